@@ -56,6 +56,13 @@ void* orc_mpc_create(const orc_config* c) {
     return h;
 }
 void orc_mpc_destroy(void* p) { delete static_cast<OrcMPC*>(p); }
+void* orc_mpc_clone(void* p) {
+    auto* src = static_cast<OrcMPC*>(p);
+    auto* h = new OrcMPC;
+    h->mpc = std::make_unique<MPCSingleRigidBody>(*src->mpc);
+    h->gait = std::make_unique<GaitOptimizer>(4);
+    return h;
+}
 const char* orc_mpc_error(void* p) { return static_cast<OrcMPC*>(p)->err.c_str(); }
 
 void orc_mpc_set_warmstart(void* p, const double* state13) {
@@ -194,11 +201,14 @@ int orc_gait_get_d(void* p, double* d) {
     return (int)v.size();
 }
 // dense parameter partials of one contact time: dA (n_eq x n), dG (n_ineq x n), db (n_eq), dh (n_ineq)
-int orc_gait_param_partials(void* p, int ee, int idx, double* dA, double* dG, double* db, double* dh) {
+// traj_src: handle whose CURRENT trajectory plays the role of the `traj` argument of ComputeParamPartialsClarabel
+// (msrb.cpp:642); pass NULL to use p's own trajectory (what mpc_controller.cpp:523-546 does)
+int orc_gait_param_partials(void* p, void* traj_src, int ee, int idx, double* dA, double* dG, double* db, double* dh) {
     auto* h = static_cast<OrcMPC*>(p);
     try {
         QPPartials pr;
-        h->gait->ComputeParamPartials(*h->mpc, h->mpc->GetTrajectory(), pr, ee, idx);
+        const Trajectory& tr = traj_src ? static_cast<OrcMPC*>(traj_src)->mpc->GetTrajectory() : h->mpc->GetTrajectory();
+        h->gait->ComputeParamPartials(*h->mpc, tr, pr, ee, idx);
         const QPData& d = h->mpc->GetQPData();
         const int n = d.num_decision_vars;
         std::memset(dA, 0, sizeof(double) * (size_t)d.num_equality * n);

@@ -51,6 +51,7 @@ def lib():
             build_oracle()
         L = C.CDLL(path)
         L.orc_mpc_create.restype = C.c_void_p
+        L.orc_mpc_clone.restype = C.c_void_p
         L.orc_mpc_error.restype = C.c_char_p
         L.orc_spline_create.restype = C.c_void_p
         L.orc_spline_clone.restype = C.c_void_p
@@ -82,12 +83,18 @@ def make_c_config(cfg):
 class OracleMPC:
     """One MPCSingleRigidBody instance of the CPU restatement."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, _h=None):
         self.cfg = cfg
         self.N = int(cfg['num_nodes'])
         self.L = lib()
-        cc = make_c_config(cfg)
-        self.h = C.c_void_p(self.L.orc_mpc_create(C.byref(cc)))
+        if _h is not None:
+            self.h = _h
+        else:
+            cc = make_c_config(cfg)
+            self.h = C.c_void_p(self.L.orc_mpc_create(C.byref(cc)))
+
+    def clone(self):
+        return OracleMPC(self.cfg, _h=C.c_void_p(self.L.orc_mpc_clone(self.h)))
 
     def __del__(self):
         try:
@@ -202,11 +209,11 @@ class OracleMPC:
         self.L.orc_gait_get_d(self.h, _d(d))
         return d
 
-    def param_partials(self, ee, idx):
+    def param_partials(self, ee, idx, traj_src=None):
         sz = self.sizes()
         dA = np.zeros((sz['n_eq'], sz['n'])); dG = np.zeros((sz['n_ineq'], sz['n']))
         db = np.zeros(sz['n_eq']); dh = np.zeros(sz['n_ineq'])
-        self._chk(self.L.orc_gait_param_partials(self.h, ee, idx, _d(dA), _d(dG), _d(db), _d(dh)))
+        self._chk(self.L.orc_gait_param_partials(self.h, traj_src.h if traj_src is not None else None, ee, idx, _d(dA), _d(dG), _d(db), _d(dh)))
         return dA, dG, db, dh
 
     def gait_optimize(self, time):
