@@ -1,0 +1,516 @@
+// Host side of the batched SRBM RTI path: the C-ABI of include/srbm_rti.h over the HIP kernels.
+// Mirrors the call sequence of mpc::MPC / mpc::MPCSingleRigidBody (reference file:line cited in the header).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "srbm_k4_update.hiph"
+#include "../../include/srbm_rti.h"
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return -1; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct srbm_batch {
+    int batch = 0, device = 0;
+    SrbmParams hp{};                 // host copy of the parameters
+    SrbmParams* dp = nullptr;
+    SrbmInst* insts = nullptr;
+    SrbmWork* works = nullptr;
+    double *d_state = nullptr, *d_time = nullptr, *d_ee = nullptr;
+    hipStream_t stream = nullptr;
+    size_t k3_lds = 0;
+    bool params_dirty = true;
+};
+
+// ---------------- small device kernels of the host protocol ----------------
+
+// default contact schedule [0,.3,.6,.9,1.2] per foot (mpc.cpp:566-608), FR and RL start in stance (trajectory.cpp:25-28),
+// three force polynomials per stance (end_effector_splines.cpp:34-153)
+__global__ void srbm_k_init(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= Pp->batch) return;
+    SrbmInst& I = insts[b];
+    const double times[5] = {0, 0.3, 0.6, 0.9, 1.2};
+    for (int ee = 0; ee < SRBM_NEE; ee++) {
+        const bool start_in_contact = (ee == 1 || ee == 2);
+        // pattern of 5 knot kinds, repeated until all contact times are placed
+        const uint8_t pat_sw[5] = {SRBM_K_LO, SRBM_K_MID, SRBM_K_TD, SRBM_K_F, SRBM_K_F};
+        const uint8_t pat_st[5] = {SRBM_K_TD, SRBM_K_F, SRBM_K_F, SRBM_K_LO, SRBM_K_MID};
+        int i = 0, j = 0, k = 1, nk = 0;
+        while (i < 5) {
+            const uint8_t kd = start_in_contact ? pat_st[j % 5] : pat_sw[j % 5];
+            double t;
+            if (kd == SRBM_K_F) {
+                const double d = times[i] - times[i - 1];
+                const double kdv = k * d;
+                const double q = kdv / 3;
+                t = times[i - 1] + q;
+                k++;
+            } else if (kd == SRBM_K_MID) {
+                const double d = times[i] - times[i - 1];
+                const double hlf = d / 2;
+                t = times[i - 1] + hlf;
+            } else {
+                t = times[i];
+                i++; k = 1;
+            }
+            I.knot_t[ee][nk] = t; I.kind[ee][nk] = kd;
+            nk++; j++;
+        }
+        I.nk[ee] = nk;
+        for (int q = nk; q < SRBM_KMAX; q++) { I.knot_t[ee][q] = 0; I.kind[ee][q] = 0; }
+        for (int c = 0; c < 3; c++) for (int q = 0; q < SRBM_KMAX; q++) { I.fval[ee][c][q][0] = 0; I.fval[ee][c][q][1] = 0; }
+        for (int c = 0; c < 2; c++) for (int q = 0; q < SRBM_KMAX; q++) I.pval[ee][c][q] = 0;
+    }
+    for (int i = 0; i < (SRBM_NMAX + 1) * 13; i++) I.states[i] = 0;
+    I.box[0] = Pp->box0[0]; I.box[1] = Pp->box0[1];
+    I.init_time = 0; I.alpha = 0; I.cost = 0; I.eq_violation = 0; I.step_norm = 0; I.qp_cost = 0; I.res_primal = 0; I.res_dual = 0; I.gap = 0;
+    I.status = SRBM_UNSOLVED; I.qp_iters = 0; I.n = 0; I.m = 0; I.n_eq = 0; I.n_ineq = 0; I.nfv = 0; I.npv = 0; I.n_td = 0; I.n_samples = 0;
+    I.err = 0; I.run_num = 0;
+}
+
+__global__ void srbm_k_warm_start(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, const double* __restrict__ states) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < (Pp->N + 1) * 13; i += blockDim.x) insts[b].states[i] = states[(size_t)b * 13 + (i % 13)];
+}
+
+// inputs of the next open-loop iteration (test/gait_opt_playground.cpp:113-126)
+__global__ void srbm_k_next_inputs(const SrbmParams* __restrict__ Pp, const SrbmInst* __restrict__ insts, double time,
+                                   double* __restrict__ state_out, double* __restrict__ time_out, double* __restrict__ ee_out) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const SrbmInst& I = insts[b];
+    if (tid < 13) state_out[(size_t)b * 13 + tid] = I.states[13 + tid];
+    if (tid == 13) time_out[b] = time;
+    if (tid >= 16 && tid < 16 + SRBM_NEE) {
+        const int ee = tid - 16;
+        FootView f{I.knot_t[ee], I.kind[ee], I.nk[ee]};
+        int err = 0;
+        double xy[2];
+        srbm_posxy_value(f, &I.pval[ee][0][0], time, xy, &err);
+        const double z = srbm_posz_value(f, time, Pp->swing_height, Pp->foot_offset, &err);
+        ee_out[(size_t)b * 12 + ee * 3] = xy[0]; ee_out[(size_t)b * 12 + ee * 3 + 1] = xy[1]; ee_out[(size_t)b * 12 + ee * 3 + 2] = z;
+    }
+}
+
+// EndEffectorSplines::SetContactTimes (end_effector_splines.cpp:860-892) for every foot of every instance
+__global__ void srbm_k_set_contact_times(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, const double* __restrict__ times, int ld) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= Pp->batch * SRBM_NEE) return;
+    const int b = w / SRBM_NEE, ee = w % SRBM_NEE;
+    SrbmInst& I = insts[b];
+    const double* ct = times + ((size_t)b * SRBM_NEE + ee) * ld;
+    int ncontact = 0;
+    for (int i = 0; i < I.nk[ee]; i++) ncontact += (I.kind[ee][i] <= SRBM_K_TD);
+    int cidx = 0;
+    for (int i = 0; i < I.nk[ee]; i++) {
+        const int kd = I.kind[ee][i];
+        if (kd <= SRBM_K_TD) {
+            double t = ct[cidx];
+            if (t < 0 && fabs(t) < 1e-3) t = 0;
+            I.knot_t[ee][i] = t; cidx++;
+        } else if (kd == SRBM_K_MID) {
+            const double d = ct[cidx] - ct[cidx - 1];
+            const double h = d / 2;
+            I.knot_t[ee][i] = I.knot_t[ee][i - 1] + h;
+        } else {
+            double contact_time = 0.2 + ct[cidx - 1];
+            if (cidx < ncontact) contact_time = ct[cidx] - ct[cidx - 1];
+            const double h = contact_time / 3;
+            I.knot_t[ee][i] = I.knot_t[ee][i - 1] + h;
+        }
+    }
+}
+
+// ---------------- host helpers ----------------
+static int upload_params(srbm_batch* h) {
+    if (!h->params_dirty) return 0;
+    HIPCHK(hipMemcpyAsync(h->dp, &h->hp, sizeof(SrbmParams), hipMemcpyHostToDevice, h->stream));
+    h->params_dirty = false;
+    return 0;
+}
+static void inv3(const double* m, double* r) {
+    const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], hh = m[7], i = m[8];
+    const double det = a * (e * i - f * hh) - b * (d * i - f * g) + c * (d * hh - e * g);
+    r[0] = (e * i - f * hh) / det; r[1] = (c * hh - b * i) / det; r[2] = (b * f - c * e) / det;
+    r[3] = (f * g - d * i) / det; r[4] = (a * i - c * g) / det; r[5] = (c * d - a * f) / det;
+    r[6] = (d * hh - e * g) / det; r[7] = (b * g - a * hh) / det; r[8] = (a * e - b * d) / det;
+}
+static int launch_step(srbm_batch* h) {
+    if (upload_params(h)) return -1;
+    const int B = h->batch;
+    hipLaunchKernelGGL(srbm_k1_assemble, dim3(B), dim3(K1_THREADS), 0, h->stream, h->dp, h->insts, h->works, h->d_state, h->d_time, h->d_ee);
+    hipLaunchKernelGGL(srbm_k2_condense, dim3(B), dim3(K2_THREADS), 0, h->stream, h->dp, h->insts, h->works);
+    hipLaunchKernelGGL(srbm_k3_ipm, dim3(B), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works);
+    hipLaunchKernelGGL(srbm_k4_update, dim3(B), dim3(K4_THREADS), 0, h->stream, h->dp, h->insts, h->works);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" {
+
+const char* srbm_last_error(void) { return g_err.c_str(); }
+long srbm_bytes_per_instance(void) { return (long)(sizeof(SrbmInst) + sizeof(SrbmWork)); }
+
+int srbm_batch_create(srbm_batch** out, int batch, const srbm_mpc_info* info, const srbm_model* model, int device) {
+    if (!out || !info || !model || batch <= 0) return fail("srbm_batch_create: bad arguments");
+    if (info->num_nodes < 5 || info->num_nodes > SRBM_NMAX) return fail("srbm_batch_create: num_nodes must be in [5, 50]");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("srbm_batch_create: no HIP device (this library has no CPU path)");
+    HIPCHK(hipSetDevice(device));
+    auto* h = new srbm_batch;
+    h->batch = batch; h->device = device;
+    SrbmParams& p = h->hp;
+    std::memset(&p, 0, sizeof(p));
+    p.batch = batch; p.N = info->num_nodes; p.max_iter = 200;
+    p.dt = info->integrator_dt; p.mu_fric = info->friction_coef; p.force_bound = info->force_bound;
+    p.swing_height = info->swing_height; p.foot_offset = info->foot_offset; p.force_cost = info->force_cost;
+    p.box0[0] = info->ee_box_size[0]; p.box0[1] = info->ee_box_size[1];
+    p.mass = model->mass;
+    std::memcpy(p.Ir, model->Ir, sizeof(p.Ir));
+    inv3(p.Ir, p.Ir_inv);
+    for (int ee = 0; ee < 4; ee++) {      // GetCOMToHip, single_rigid_body_model.cpp:289-305
+        double x = model->hip_xy[2 * ee], y = model->hip_xy[2 * ee + 1];
+        if (y >= 0) y += 0.1; else y -= 0.1;
+        x += 0.025;
+        p.hip[2 * ee] = x; p.hip[2 * ee + 1] = y;
+    }
+    p.merit_mu = 5000; p.td_fraction = 0.75;
+    p.tol_gap_abs = 1e-8; p.tol_gap_rel = 1e-8; p.tol_feas = 1e-10;     // clarabel_interface.cpp:21-23
+    HIPCHK(hipStreamCreate(&h->stream));
+    HIPCHK(hipMalloc(&h->dp, sizeof(SrbmParams)));
+    HIPCHK(hipMalloc(&h->insts, sizeof(SrbmInst) * (size_t)batch));
+    HIPCHK(hipMalloc(&h->works, sizeof(SrbmWork) * (size_t)batch));
+    HIPCHK(hipMalloc(&h->d_state, sizeof(double) * 13 * (size_t)batch));
+    HIPCHK(hipMalloc(&h->d_time, sizeof(double) * (size_t)batch));
+    HIPCHK(hipMalloc(&h->d_ee, sizeof(double) * 12 * (size_t)batch));
+    HIPCHK(hipMemsetAsync(h->works, 0, sizeof(SrbmWork) * (size_t)batch, h->stream));
+    h->k3_lds = srbm_k3_lds_bytes(p.N);
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_ipm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
+    if (upload_params(h)) { delete h; return -1; }
+    hipLaunchKernelGGL(srbm_k_init, dim3((batch + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *out = h;
+    return 0;
+}
+
+int srbm_batch_destroy(srbm_batch* h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->dp); (void)hipFree(h->insts); (void)hipFree(h->works);
+    (void)hipFree(h->d_state); (void)hipFree(h->d_time); (void)hipFree(h->d_ee);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int srbm_add_quadratic_tracking_cost(srbm_batch* h, const double* state_des12, const double* Q144) {
+    if (!h || !state_des12 || !Q144) return fail("bad arguments");
+    std::memcpy(h->hp.Q, Q144, sizeof(double) * 144);
+    for (int i = 0; i < 12; i++) {
+        double a = 0;
+        for (int j = 0; j < 12; j++) a += Q144[i * 12 + j] * state_des12[j];
+        h->hp.w[i] = -1 * a;
+    }
+    h->params_dirty = true;
+    return 0;
+}
+int srbm_set_quadratic_final_cost(srbm_batch* h, const double* Phi144) {
+    if (!h || !Phi144) return fail("bad arguments");
+    std::memcpy(h->hp.Phi, Phi144, sizeof(double) * 144);
+    h->params_dirty = true;
+    return 0;
+}
+int srbm_set_linear_final_cost(srbm_batch* h, const double* w12) {
+    if (!h || !w12) return fail("bad arguments");
+    std::memcpy(h->hp.Phi_w, w12, sizeof(double) * 12);
+    h->params_dirty = true;
+    return 0;
+}
+int srbm_set_solver_tolerances(srbm_batch* h, double ga, double gr, double tf, int max_iter) {
+    if (!h) return fail("bad arguments");
+    h->hp.tol_gap_abs = ga; h->hp.tol_gap_rel = gr; h->hp.tol_feas = tf; h->hp.max_iter = max_iter;
+    h->params_dirty = true;
+    return 0;
+}
+int srbm_set_state_trajectory_warm_start(srbm_batch* h, const double* states) {
+    if (!h || !states) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    HIPCHK(hipMemcpyAsync(h->d_state, states, sizeof(double) * 13 * (size_t)h->batch, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(srbm_k_warm_start, dim3(h->batch), dim3(64), 0, h->stream, h->dp, h->insts, h->d_state);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static int upload_inputs(srbm_batch* h, const double* state, const double* init_time, const double* ee) {
+    const size_t B = h->batch;
+    HIPCHK(hipMemcpyAsync(h->d_state, state, sizeof(double) * 13 * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_ee, ee, sizeof(double) * 12 * B, hipMemcpyHostToDevice, h->stream));
+    if (init_time) HIPCHK(hipMemcpyAsync(h->d_time, init_time, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+    else HIPCHK(hipMemsetAsync(h->d_time, 0, sizeof(double) * B, h->stream));
+    return 0;
+}
+
+int srbm_create_initial_run(srbm_batch* h, const double* state, const double* ee) {
+    if (!h || !state || !ee) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_inputs(h, state, nullptr, ee)) return -1;
+    for (int it = 0; it < 10; it++) if (launch_step(h)) return -1;     // mpc.cpp:85-88: always 10 solves
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int srbm_get_real_time_update(srbm_batch* h, const double* state, const double* init_time, const double* ee) {
+    if (!h || !state || !init_time || !ee) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_inputs(h, state, init_time, ee)) return -1;
+    if (launch_step(h)) return -1;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int srbm_get_real_time_update_dev(srbm_batch* h, const double* state_dev, const double* time_dev, const double* ee_dev) {
+    if (!h || !state_dev || !time_dev || !ee_dev) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t B = h->batch;
+    HIPCHK(hipMemcpyAsync(h->d_state, state_dev, sizeof(double) * 13 * B, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_ee, ee_dev, sizeof(double) * 12 * B, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_time, time_dev, sizeof(double) * B, hipMemcpyDeviceToDevice, h->stream));
+    return launch_step(h);
+}
+int srbm_rti_advance(srbm_batch* h, int first_index, int steps) {
+    if (!h || steps < 0) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    for (int i = 0; i < steps; i++) {
+        const double time = (first_index + i) * h->hp.dt;      // double time = i*info.integrator_dt (gait_opt_playground.cpp:84)
+        hipLaunchKernelGGL(srbm_k_next_inputs, dim3(h->batch), dim3(64), 0, h->stream, h->dp, h->insts, time, h->d_state, h->d_time, h->d_ee);
+        if (launch_step(h)) return -1;
+    }
+    return 0;
+}
+int srbm_synchronize(srbm_batch* h) {
+    if (!h) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+void* srbm_stream(srbm_batch* h) { return h ? (void*)h->stream : nullptr; }
+
+int srbm_update_contact_times(srbm_batch* h, const double* times, int max_contacts) {
+    if (!h || !times || max_contacts <= 0) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    double* d = nullptr;
+    const size_t bytes = sizeof(double) * (size_t)h->batch * SRBM_NEE * max_contacts;
+    HIPCHK(hipMalloc(&d, bytes));
+    HIPCHK(hipMemcpyAsync(d, times, bytes, hipMemcpyHostToDevice, h->stream));
+    if (upload_params(h)) return -1;
+    const int tot = h->batch * SRBM_NEE;
+    hipLaunchKernelGGL(srbm_k_set_contact_times, dim3((tot + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts, d, max_contacts);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipFree(d));
+    return 0;
+}
+
+// ---------------- getters ----------------
+static int fetch_insts(srbm_batch* h, std::vector<SrbmInst>& v) {
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    v.resize(h->batch);
+    HIPCHK(hipMemcpy(v.data(), h->insts, sizeof(SrbmInst) * (size_t)h->batch, hipMemcpyDeviceToHost));
+    return 0;
+}
+int srbm_get_sizes(srbm_batch* h, int* sizes) {
+    if (!h || !sizes) return fail("bad arguments");
+    std::vector<SrbmInst> v;
+    if (fetch_insts(h, v)) return -1;
+    for (int b = 0; b < h->batch; b++) {
+        int* s = sizes + 8 * b;
+        s[0] = v[b].n; s[1] = v[b].m; s[2] = v[b].n_eq; s[3] = v[b].n_ineq; s[4] = v[b].nfv; s[5] = v[b].npv; s[6] = v[b].n_td; s[7] = v[b].n_samples;
+    }
+    return 0;
+}
+int srbm_get_status(srbm_batch* h, int* status, int* err) {
+    if (!h || !status) return fail("bad arguments");
+    std::vector<SrbmInst> v;
+    if (fetch_insts(h, v)) return -1;
+    for (int b = 0; b < h->batch; b++) { status[b] = v[b].status; if (err) err[b] = v[b].err; }
+    return 0;
+}
+int srbm_get_stats(srbm_batch* h, double* stats) {
+    if (!h || !stats) return fail("bad arguments");
+    std::vector<SrbmInst> v;
+    if (fetch_insts(h, v)) return -1;
+    for (int b = 0; b < h->batch; b++) {
+        double* s = stats + 8 * b;
+        s[0] = v[b].alpha; s[1] = v[b].cost; s[2] = v[b].eq_violation; s[3] = v[b].step_norm; s[4] = v[b].qp_iters;
+        s[5] = v[b].res_primal; s[6] = v[b].res_dual; s[7] = v[b].gap;
+    }
+    return 0;
+}
+int srbm_get_trajectory_states(srbm_batch* h, double* states) {
+    if (!h || !states) return fail("bad arguments");
+    std::vector<SrbmInst> v;
+    if (fetch_insts(h, v)) return -1;
+    const int len = (h->hp.N + 1) * 13;
+    for (int b = 0; b < h->batch; b++) std::memcpy(states + (size_t)b * len, v[b].states, sizeof(double) * len);
+    return 0;
+}
+static int fetch_work_field(srbm_batch* h, size_t offset, size_t count, double* out, int ld) {
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((size_t)ld < count) return fail("leading dimension too small");
+    HIPCHK(hipMemcpy2D(out, sizeof(double) * ld, reinterpret_cast<const char*>(h->works) + offset, sizeof(SrbmWork), sizeof(double) * count,
+                       h->batch, hipMemcpyDeviceToHost));
+    return 0;
+}
+int srbm_get_qp_solution(srbm_batch* h, double* x, int ld) {
+    if (!h || !x) return fail("bad arguments");
+    return fetch_work_field(h, offsetof(SrbmWork, x), std::min<size_t>(ld, SRBM_NXMAX), x, ld);
+}
+int srbm_get_raw_qp_minimiser(srbm_batch* h, double* x, int ld) {
+    if (!h || !x) return fail("bad arguments");
+    return fetch_work_field(h, offsetof(SrbmWork, x_qp), std::min<size_t>(ld, SRBM_NXMAX), x, ld);
+}
+int srbm_get_dual_solution(srbm_batch* h, double* z, double* s, int ld) {
+    if (!h || !z) return fail("bad arguments");
+    if (fetch_work_field(h, offsetof(SrbmWork, z), std::min<size_t>(ld, SRBM_MMAX), z, ld)) return -1;
+    if (s) return fetch_work_field(h, offsetof(SrbmWork, s), std::min<size_t>(ld, SRBM_MMAX), s, ld);
+    return 0;
+}
+int srbm_get_knots(srbm_batch* h, int inst, double* times, int* kinds, int* nk, double* fvals, double* pvals, double* box) {
+    if (!h || inst < 0 || inst >= h->batch) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<SrbmInst> v(1);
+    HIPCHK(hipMemcpy(v.data(), h->insts + inst, sizeof(SrbmInst), hipMemcpyDeviceToHost));
+    const SrbmInst& I = v[0];
+    for (int ee = 0; ee < SRBM_NEE; ee++) {
+        if (nk) nk[ee] = I.nk[ee];
+        for (int k = 0; k < SRBM_KMAX; k++) {
+            if (times) times[ee * SRBM_KMAX + k] = I.knot_t[ee][k];
+            if (kinds) kinds[ee * SRBM_KMAX + k] = I.kind[ee][k];
+        }
+    }
+    if (fvals) std::memcpy(fvals, I.fval, sizeof(I.fval));
+    if (pvals) std::memcpy(pvals, I.pval, sizeof(I.pval));
+    if (box) { box[0] = I.box[0]; box[1] = I.box[1]; }
+    return 0;
+}
+
+// Dense expansion of the structured QP into the reference's row/column layout.
+int srbm_export_qp(srbm_batch* h, int inst, double* A, double* b, double* Pm, double* q) {
+    if (!h || inst < 0 || inst >= h->batch) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<SrbmInst> vi(1);
+    std::vector<SrbmWork> vw(1);
+    HIPCHK(hipMemcpy(vi.data(), h->insts + inst, sizeof(SrbmInst), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(vw.data(), h->works + inst, sizeof(SrbmWork), hipMemcpyDeviceToHost));
+    const SrbmInst& I = vi[0];
+    const SrbmWork& W = vw[0];
+    const SrbmParams& P = h->hp;
+    const int N = P.N, n = I.n, m = I.m, nx = (N + 1) * 12, ns = W.n_samp;
+    const double dt = P.dt;
+    if (A) std::memset(A, 0, sizeof(double) * (size_t)m * n);
+    if (b) std::memset(b, 0, sizeof(double) * m);
+    if (Pm) std::memset(Pm, 0, sizeof(double) * (size_t)n * n);
+    if (q) std::memset(q, 0, sizeof(double) * n);
+    auto Aat = [&](int r, int c) -> double& { return A[(size_t)r * n + c]; };
+    if (A && b) {
+        // dynamics rows (msrb.cpp:218-265)
+        for (int i = 0; i < 12; i++) { Aat(i, i) = -1; b[i] = -W.xbar[i]; }
+        for (int k = 0; k < N; k++) {
+            const int r0 = 12 * (k + 1);
+            for (int i = 0; i < 12; i++) { Aat(r0 + i, 12 * k + i) += 1.0; Aat(r0 + i, 12 * (k + 1) + i) += -1.0; b[r0 + i] = -W.craw[k][i]; }
+            for (int i = 0; i < 3; i++) Aat(r0 + i, 12 * k + 3 + i) += dt * (1.0 / P.mass);
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+                Aat(r0 + 6 + i, 12 * k + 9 + j) += dt * P.Ir_inv[3 * i + j];
+                Aat(r0 + 9 + i, 12 * k + j) += dt * W.ALp[k][3 * i + j];
+                Aat(r0 + 9 + i, 12 * k + 9 + j) += dt * W.ALL[k][3 * i + j];
+            }
+            for (int ee = 0; ee < SRBM_NEE; ee++) {
+                const SrbmNodeRec& r = W.node[k][ee];
+                const double d[3] = {r.r[0] - W.xbar[12 * k], r.r[1] - W.xbar[12 * k + 1], r.r[2] - W.xbar[12 * k + 2]};
+                for (int c = 0; c < 3; c++) {
+                    double e[3] = {0, 0, 0}; e[c] = 1;
+                    const double dxe[3] = {d[1] * e[2] - d[2] * e[1], d[2] * e[0] - d[0] * e[2], d[0] * e[1] - d[1] * e[0]};
+                    if (r.fmut) for (int p = 0; p < r.fcnt; p++) {
+                        const int col = nx + W.fbase[ee][c] + r.fidx + p;
+                        Aat(r0 + 3 + c, col) = dt * r.flin[p];
+                        for (int qd = 0; qd < 3; qd++) Aat(r0 + 9 + qd, col) = dt * (dxe[qd] * r.flin[p]);
+                    }
+                    if (c < 2) {
+                        const double exf[3] = {e[1] * r.f[2] - e[2] * r.f[1], e[2] * r.f[0] - e[0] * r.f[2], e[0] * r.f[1] - e[1] * r.f[0]};
+                        for (int p = 0; p < r.pcnt; p++) {
+                            const int col = nx + W.pbase[ee][c] + r.pidx + p;
+                            for (int qd = 0; qd < 3; qd++) Aat(r0 + 9 + qd, col) = dt * (exf[qd] * r.plin[p]);
+                        }
+                    }
+                }
+            }
+        }
+        // force box + friction pyramid (mpc.cpp:352-414, 166-208; qp_data.cpp:256)
+        int row = nx;
+        for (int j = 0; j < 2; j++)
+            for (int s = 0; s < ns; s++) {
+                const SrbmSample& sm = W.samp[s];
+                for (int p = 0; p < sm.cnt; p++) Aat(row, nx + W.fbase[sm.ee][2] + sm.idx + p) = (j == 0 ? 1.0 : -1.0) * sm.phi[p];
+                b[row] = j == 0 ? P.force_bound : 0.0;
+                row++;
+            }
+        const double mu = P.mu_fric;
+        const double pyr[4][3] = {{1, 0, -mu}, {-1, 0, -mu}, {0, 1, -mu}, {0, -1, -mu}};
+        for (int s = 0; s < ns; s++) {
+            const SrbmSample& sm = W.samp[s];
+            for (int fc = 0; fc < 4; fc++) {
+                for (int c = 0; c < 3; c++) {
+                    if (pyr[fc][c] == 0) continue;
+                    for (int p = 0; p < sm.cnt; p++) Aat(row, nx + W.fbase[sm.ee][c] + sm.idx + p) = pyr[fc][c] * sm.phi[p];
+                }
+                b[row] = 0;
+                row++;
+            }
+        }
+        // foot box (msrb.cpp:381-443; qp_data.cpp:240)
+        for (int i = 0; i < 2; i++)
+            for (int k = 4; k <= N; k++)
+                for (int ee = 0; ee < SRBM_NEE; ee++)
+                    for (int c = 0; c < 2; c++) {
+                        const SrbmNodeRec& r = W.node[k][ee];
+                        Aat(row, 12 * k + c) = (i == 0) ? -1 : 1;
+                        for (int p = 0; p < r.pcnt; p++) Aat(row, nx + W.pbase[ee][c] + r.pidx + p) = (i == 0) ? r.plin[p] : -r.plin[p];
+                        const double half = W.box_used[c] / 2, hip = P.hip[2 * ee + c];
+                        b[row] = (i == 0) ? (half + hip) : -(-half + hip);
+                        row++;
+                    }
+        // TD rows then start rows
+        for (int e = 0; e < W.n_td + 8; e++) {
+            for (int p = 0; p < W.eq_cnt[e]; p++) Aat(row, nx + W.eq_idx[e] + p) = W.eq_coef[e][p];
+            b[row] = W.eq_rhs[e];
+            row++;
+        }
+        if (row != m) return fail("srbm_export_qp: row count mismatch");
+    }
+    if (Pm && q) {
+        for (int k = 0; k <= N; k++) {
+            const double* Qk = (k == N) ? P.Phi : P.Q;
+            const double* wk = (k == N) ? P.Phi_w : P.w;
+            for (int i = 0; i < 12; i++) {
+                for (int j = 0; j < 12; j++) Pm[(size_t)(12 * k + i) * n + 12 * k + j] += Qk[12 * i + j];
+                q[12 * k + i] = wk[i];
+            }
+        }
+        for (int j = 0; j < W.nf; j++) Pm[(size_t)(nx + j) * n + nx + j] += P.force_cost;
+        for (int i = 0; i < n; i++) Pm[(size_t)i * n + i] += 1e-3;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+// Shared host/device data layout of the batched SRBM real-time-iteration path (MI355X / gfx950).
+//
+// One "instance" = one mpc::MPCSingleRigidBody of the reference (/root/reference/mpc/include/mpc_single_rigid_body.h:11-76):
+//   SrbmInst  -- the persistent part (what the reference keeps in prev_traj_ + solver status): node states, the four
+//                per-foot knot tables (times, knot kinds, force/position node values), the current foot-box size.
+//   SrbmWork  -- per-solve scratch that lives in HBM/L2 between the kernels of one RTI step (structured QP:
+//                per-node linearisation records, condensed Hessian, dense state rows of the foot-box constraints,
+//                inequality sample tables, primal/dual iterates).
+// Everything is fp64 (the reference computes in Eigen::VectorXd) + int32 indices.
+#pragma once
+#include <stdint.h>
+
+#define SRBM_NEE 4
+#define SRBM_NMAX 50          /* horizon nodes (reference configs use 10 / 20 / 50) */
+#define SRBM_KMAX 32          /* knots per foot inside the horizon window */
+#define SRBM_NUMAX 160        /* spline (input) variables */
+#define SRBM_NSMAX 120        /* force samples: FB_PER_FORCE(10) x stance phases in the window */
+#define SRBM_NEEROW (2 * (SRBM_NMAX - 3))          /* dense state rows: (node 4..N) x (x,y) */
+#define SRBM_MIMAX (6 * SRBM_NSMAX + 16 * (SRBM_NMAX - 3))
+#define SRBM_NXMAX ((SRBM_NMAX + 1) * 12 + SRBM_NUMAX)
+#define SRBM_MMAX ((SRBM_NMAX + 1) * 12 + SRBM_MIMAX + 16)
+#define SRBM_HPACK (SRBM_NUMAX * (SRBM_NUMAX + 1) / 2)
+
+/* knot kinds (end_effector_splines.cpp:45-100 pattern): force / position-xy / position-z node types follow from the kind */
+enum { SRBM_K_LO = 0, SRBM_K_TD = 1, SRBM_K_F = 2, SRBM_K_MID = 3 };
+
+/* mpc::SolveQuality, /root/reference/mpc/include/qp/qp_interface.h:12-22 */
+enum { SRBM_SOLVED = 0, SRBM_SOLVED_INACC = 1, SRBM_MAX_ITER = 2, SRBM_PRIMAL_INFEASIBLE = 3, SRBM_DUAL_INFEASIBLE = 4,
+       SRBM_PRIMAL_INFEASIBLE_INACC = 5, SRBM_DUAL_INFEASIBLE_INACC = 6, SRBM_UNSOLVED = 7, SRBM_OTHER = 8 };
+
+/* error bits (SrbmInst.err): conditions on which the reference throws */
+enum { SRBM_ERR_TIME_SMALL = 1, SRBM_ERR_TIME_LARGE = 2, SRBM_ERR_INVALID_TIME = 4, SRBM_ERR_FORCE_NOT_MUTABLE = 8,
+       SRBM_ERR_CAPACITY = 16, SRBM_ERR_REMOVE_POLY = 32, SRBM_ERR_TD_INDEX = 64, SRBM_ERR_CHOLESKY = 128 };
+
+typedef struct SrbmParams {
+    int batch, N;
+    int max_iter, pad0;
+    double dt, mu_fric, force_bound, swing_height, foot_offset, force_cost;
+    double box0[2];                 /* configured ee_box_size (ee_bounds_, msrb.cpp:22) */
+    double mass, Ir[9], Ir_inv[9];
+    double hip[8];                  /* GetCOMToHip(ee).xy, single_rigid_body_model.cpp:258-308 */
+    double Q[144], w[12], Phi[144], Phi_w[12];
+    double merit_mu, td_fraction;   /* mpc.cpp:65, :73 */
+    double tol_gap_abs, tol_gap_rel, tol_feas;
+} SrbmParams;
+
+typedef struct SrbmInst {
+    double states[(SRBM_NMAX + 1) * 13];          /* manifold states [p, lin-mom, quat xyzw, ang-mom] */
+    double knot_t[SRBM_NEE][SRBM_KMAX];
+    double fval[SRBM_NEE][3][SRBM_KMAX][2];       /* force node (value, slope/FORCE_MULT) */
+    double pval[SRBM_NEE][2][SRBM_KMAX];          /* position xy node values */
+    double box[2];
+    double init_time;
+    double alpha, cost, eq_violation, step_norm, qp_cost, res_primal, res_dual, gap;
+    int nk[SRBM_NEE];
+    uint8_t kind[SRBM_NEE][SRBM_KMAX];
+    int status, qp_iters, n, m, n_eq, n_ineq, nfv, npv, n_td, n_samples, err, run_num;
+} SrbmInst;
+
+/* per (node, foot) linearisation record */
+typedef struct SrbmNodeRec {
+    double f[3];        /* force at the node time */
+    double r[3];        /* foot location at the node time */
+    double flin[4];     /* Hermite basis coefficients of the force variables (same for x,y,z) */
+    double plin[2];     /* basis coefficients of the position variables (same for x,y) */
+    int fidx, fcnt, fmut, pidx, pcnt, pad;   /* indices local to the (foot, coord) variable block */
+} SrbmNodeRec;
+
+typedef struct SrbmSample {   /* one force sample time (10 per stance phase): rows of ForceBox + FrictionCone */
+    double phi[4];
+    int idx, cnt, ee, pad;
+} SrbmSample;
+
+typedef struct SrbmWork {
+    /* ---- assembly (kernel 1) ---- */
+    SrbmNodeRec node[SRBM_NMAX + 1][SRBM_NEE];
+    double ALp[SRBM_NMAX][9], ALL[SRBM_NMAX][9];  /* continuous-time blocks dL/dp, dL/dL of A_k */
+    double cbar[SRBM_NMAX][12];                   /* dt*C_k + columns of fixed / substituted variables */
+    double craw[SRBM_NMAX][12];                   /* dt*C_k */
+    double xbar[(SRBM_NMAX + 1) * 12];            /* tangent states of the linearisation point */
+    double u_prev[SRBM_NUMAX];                    /* spline variables of the linearisation point */
+    SrbmSample samp[SRBM_NSMAX];
+    double eq_rhs[16];                            /* TD rows then start rows (reference order) */
+    double eq_coef[16][2];
+    int eq_idx[16], eq_cnt[16];
+    double fix_val[SRBM_NUMAX];                   /* value of pinned variables */
+    double sub_kappa[SRBM_NUMAX], sub_rho[SRBM_NUMAX];
+    int fix_mask[SRBM_NUMAX];                     /* 1: pinned to fix_val, 2: u_j = kappa + rho*u_{sub_src}, 0: free */
+    int sub_src[SRBM_NUMAX];                      /* for a free column: index of a variable substituted INTO it, or -1 */
+    int sub_tgt[SRBM_NUMAX];                      /* for a substituted variable: the free variable it depends on */
+    int col_ee[SRBM_NUMAX], col_type[SRBM_NUMAX], col_coord[SRBM_NUMAX], col_local[SRBM_NUMAX];
+    int fbase[SRBM_NEE][3], pbase[SRBM_NEE][2], nfv_ee[SRBM_NEE], npv_ee[SRBM_NEE];
+    int nu, nf, np, n_samp, n_td, n_eq_u, td_ee_mask, pad1;
+    double box_used[2];                           /* foot-box size in effect for this solve */
+    /* ---- condensing (kernel 2) ---- */
+    double H[SRBM_HPACK];                         /* reduced Hessian, packed lower, row-major */
+    double g[SRBM_NUMAX];
+    double Sig[SRBM_NEEROW][SRBM_NUMAX];          /* rows c of S_k, k=4..N, c in {x,y}: row index 2*(k-4)+c */
+    double sig0[SRBM_NEEROW];                     /* affine part s_k[c] */
+    /* ---- IPM (kernel 3) ---- */
+    double u[SRBM_NUMAX];                         /* QP minimiser, spline variables (full vector incl. pinned) */
+    double lam[SRBM_MIMAX], slack[SRBM_MIMAX];
+    /* ---- recovery (kernel 4) ---- */
+    double x_qp[SRBM_NXMAX];                      /* raw QP minimiser in the reference's decision-vector layout */
+    double x[SRBM_NXMAX];                         /* prev_qp_sol after the line search */
+    double z[SRBM_MMAX];                          /* dual vector in the reference's row order */
+    double s[SRBM_MMAX];
+} SrbmWork;

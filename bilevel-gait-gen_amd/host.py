@@ -1,0 +1,236 @@
+"""Python binding of the C-ABI in include/srbm_rti.h (libsrbm_rti.so, HIP/gfx950).
+
+`BatchMPC` mirrors the public surface of the reference's mpc::MPCSingleRigidBody for a batch of instances
+(/root/reference/mpc/include/mpc.h:70-170, mpc_single_rigid_body.h:11-76): same method names (snake_case), same
+argument meaning.  There is NO CPU fallback: if the HIP library or a GPU is missing this module raises.
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libsrbm_rti.so')
+CONFIG_DIR = os.path.join(HERE, 'configs')
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+SOLVE_QUALITY = ['Solved', 'SolvedInacc', 'MaxIter', 'PrimalInfeasible', 'DualInfeasible', 'PrimalInfeasibleInacc',
+                 'DualInfeasibleInacc', 'Unsolved', 'Other']
+
+
+class MPCInfo(C.Structure):          # srbm_mpc_info
+    _fields_ = [('num_nodes', C.c_int), ('integrator_dt', C.c_double), ('friction_coef', C.c_double),
+                ('force_bound', C.c_double), ('swing_height', C.c_double), ('foot_offset', C.c_double),
+                ('ee_box_size', C.c_double * 2), ('force_cost', C.c_double)]
+
+
+class Model(C.Structure):            # srbm_model
+    _fields_ = [('mass', C.c_double), ('Ir', C.c_double * 9), ('hip_xy', C.c_double * 8)]
+
+
+def build(force=False):
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(['make', '-s', '-C', os.path.join(HERE, 'csrc')])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError('libsrbm_rti.so is not built (run __graft_entry__.build()); there is no CPU fallback')
+        L = C.CDLL(LIB_PATH)
+        L.srbm_last_error.restype = C.c_char_p
+        L.srbm_stream.restype = C.c_void_p
+        L.srbm_bytes_per_instance.restype = C.c_long
+        _lib = L
+    return _lib
+
+
+def load_config(name='a1_configuration', **overrides):
+    cfg = json.load(open(os.path.join(CONFIG_DIR, name + '.json')))
+    cfg.update(overrides)
+    return cfg
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def quat_log3(q):
+    """log of a unit quaternion (xyzw) -- closed form of pinocchio::quaternion::log3"""
+    v = np.asarray(q[:3], float)
+    n = np.linalg.norm(v)
+    w = q[3]
+    if n < 1e-8:
+        return (2.0 / w) * (1.0 - n * n / (3.0 * w * w)) * v
+    th = 2.0 * np.arctan2(n, w) if w >= 0 else -2.0 * np.arctan2(n, -w)
+    return th / n * v
+
+
+def manifold_to_tangent(s13):
+    s13 = np.asarray(s13, float)
+    return np.concatenate([s13[:6], quat_log3(s13[6:10]), s13[10:13]])
+
+
+class BatchMPC:
+    """batch x mpc::MPCSingleRigidBody on one MI355X."""
+
+    def __init__(self, cfg, batch, device=0):
+        self.L = lib()
+        self.cfg = cfg
+        self.batch = int(batch)
+        self.N = int(cfg['num_nodes'])
+        info = MPCInfo()
+        info.num_nodes = self.N
+        info.integrator_dt = cfg['integrator_dt']
+        info.friction_coef = cfg['friction_coef']
+        info.force_bound = cfg['force_bound']
+        info.swing_height = cfg['swing_height']
+        info.foot_offset = cfg['foot_offset']
+        info.ee_box_size[:] = [float(v) for v in cfg['ee_box_size']]
+        info.force_cost = cfg['force_cost']
+        model = Model()
+        model.mass = cfg['mass']
+        model.Ir[:] = list(np.asarray(cfg['Ir'], float).reshape(-1))
+        model.hip_xy[:] = list(np.asarray(cfg['hip_xy'], float).reshape(-1))
+        self.h = C.c_void_p()
+        self._chk(self.L.srbm_batch_create(C.byref(self.h), self.batch, C.byref(info), C.byref(model), int(device)))
+        # cost set-up exactly as the caller does it: /root/reference/controllers/mpc_controller.cpp:57-67
+        Q = np.diag(np.asarray(cfg['Q_srbd_diag'], float))
+        des = manifold_to_tangent(cfg['srb_target'])
+        self.add_quadratic_tracking_cost(des, Q)
+        self.set_quadratic_final_cost(Q)
+        self.set_linear_final_cost(-1 * Q @ des)
+
+    def close(self):
+        if self.h:
+            self.L.srbm_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError('srbm: ' + self.L.srbm_last_error().decode())
+
+    # ---- set-up (mpc.h:92-110) ----
+    def add_quadratic_tracking_cost(self, state_des12, Q):
+        a = np.ascontiguousarray(state_des12, dtype=np.float64); q = np.ascontiguousarray(Q, dtype=np.float64)
+        self._chk(self.L.srbm_add_quadratic_tracking_cost(self.h, _d(a), _d(q)))
+
+    def set_quadratic_final_cost(self, Phi):
+        q = np.ascontiguousarray(Phi, dtype=np.float64)
+        self._chk(self.L.srbm_set_quadratic_final_cost(self.h, _d(q)))
+
+    def set_linear_final_cost(self, w):
+        a = np.ascontiguousarray(w, dtype=np.float64)
+        self._chk(self.L.srbm_set_linear_final_cost(self.h, _d(a)))
+
+    def set_state_trajectory_warm_start(self, states):
+        a = self._bcast(states, 13)
+        self._chk(self.L.srbm_set_state_trajectory_warm_start(self.h, _d(a)))
+
+    def set_solver_tolerances(self, gap_abs, gap_rel, feas, max_iter=200):
+        self._chk(self.L.srbm_set_solver_tolerances(self.h, C.c_double(gap_abs), C.c_double(gap_rel), C.c_double(feas), int(max_iter)))
+
+    def _bcast(self, a, width):
+        a = np.asarray(a, dtype=np.float64)
+        if a.size == width:
+            a = np.tile(a.reshape(1, width), (self.batch, 1))
+        return np.ascontiguousarray(a.reshape(self.batch, width))
+
+    # ---- solves ----
+    def create_initial_run(self, state, ee):
+        s = self._bcast(state, 13); e = self._bcast(ee, 12)
+        self._chk(self.L.srbm_create_initial_run(self.h, _d(s), _d(e)))
+
+    def get_real_time_update(self, state, init_time, ee):
+        s = self._bcast(state, 13); e = self._bcast(ee, 12)
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(init_time, dtype=np.float64), (self.batch,)))
+        self._chk(self.L.srbm_get_real_time_update(self.h, _d(s), _d(t), _d(e)))
+
+    def get_real_time_update_dev(self, state_ptr, time_ptr, ee_ptr):
+        self._chk(self.L.srbm_get_real_time_update_dev(self.h, C.c_void_p(state_ptr), C.c_void_p(time_ptr), C.c_void_p(ee_ptr)))
+
+    def rti_advance(self, first_index, steps):
+        self._chk(self.L.srbm_rti_advance(self.h, int(first_index), int(steps)))
+
+    def synchronize(self):
+        self._chk(self.L.srbm_synchronize(self.h))
+
+    def stream(self):
+        return self.L.srbm_stream(self.h)
+
+    def update_contact_times(self, times):
+        a = np.ascontiguousarray(times, dtype=np.float64)
+        assert a.ndim == 3 and a.shape[0] == self.batch and a.shape[1] == 4
+        self._chk(self.L.srbm_update_contact_times(self.h, _d(a), a.shape[2]))
+
+    # ---- results ----
+    def sizes(self):
+        a = np.zeros((self.batch, 8), np.int32)
+        self._chk(self.L.srbm_get_sizes(self.h, _i(a)))
+        return a
+
+    def status(self):
+        s = np.zeros(self.batch, np.int32); e = np.zeros(self.batch, np.int32)
+        self._chk(self.L.srbm_get_status(self.h, _i(s), _i(e)))
+        return s, e
+
+    def stats(self):
+        a = np.zeros((self.batch, 8))
+        self._chk(self.L.srbm_get_stats(self.h, _d(a)))
+        return a
+
+    def qp_solution(self):
+        ld = (self.N + 1) * 12 + 160
+        a = np.zeros((self.batch, ld))
+        self._chk(self.L.srbm_get_qp_solution(self.h, _d(a), ld))
+        return a
+
+    def raw_qp_minimiser(self):
+        ld = (self.N + 1) * 12 + 160
+        a = np.zeros((self.batch, ld))
+        self._chk(self.L.srbm_get_raw_qp_minimiser(self.h, _d(a), ld))
+        return a
+
+    def dual_solution(self):
+        ld = (self.N + 1) * 12 + 6 * 120 + 16 * (self.N - 3) + 16
+        z = np.zeros((self.batch, ld)); s = np.zeros((self.batch, ld))
+        self._chk(self.L.srbm_get_dual_solution(self.h, _d(z), _d(s), ld))
+        return z, s
+
+    def trajectory_states(self):
+        a = np.zeros((self.batch, self.N + 1, 13))
+        self._chk(self.L.srbm_get_trajectory_states(self.h, _d(a)))
+        return a
+
+    def knots(self, inst):
+        t = np.zeros((4, 32)); kd = np.zeros((4, 32), np.int32); nk = np.zeros(4, np.int32)
+        fv = np.zeros((4, 3, 32, 2)); pv = np.zeros((4, 2, 32)); box = np.zeros(2)
+        self._chk(self.L.srbm_get_knots(self.h, int(inst), _d(t), _i(kd), _i(nk), _d(fv), _d(pv), _d(box)))
+        return dict(times=t, kinds=kd, nk=nk, fvals=fv, pvals=pv, box=box)
+
+    def export_qp(self, inst):
+        sz = self.sizes()[inst]
+        n, m = int(sz[0]), int(sz[1])
+        A = np.zeros((m, n)); b = np.zeros(m); P = np.zeros((n, n)); q = np.zeros(n)
+        self._chk(self.L.srbm_export_qp(self.h, int(inst), _d(A), _d(b), _d(P), _d(q)))
+        return A, b, P, q

@@ -1,0 +1,93 @@
+/* C-ABI of the MI355X-native batched SRBM real-time-iteration path (libsrbm_rti.so).
+ *
+ * Every entry point replaces, for a BATCH of independent MPC instances, one public method of the reference's
+ * mpc::MPC / mpc::MPCSingleRigidBody (cited per function, paths relative to /root/reference).  Instance b of the batch
+ * is exactly one reference object: same constructor arguments (srbm_mpc_info + model constants), same default contact
+ * schedule, same state.  Plain pointers and sizes only; all array arguments are HOST pointers unless the function
+ * name ends in _dev.  Return value: 0 on success, negative on error (srbm_last_error() gives the text).
+ * The library fails loudly: there is no CPU fallback of any kind.
+ */
+#ifndef SRBM_RTI_H
+#define SRBM_RTI_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct srbm_batch srbm_batch;
+
+/* mpc::MPCInfo, mpc/include/mpc.h:39-62 (fields that affect the live SRBM path) */
+typedef struct srbm_mpc_info {
+    int num_nodes;
+    double integrator_dt, friction_coef, force_bound, swing_height, foot_offset;
+    double ee_box_size[2];
+    double force_cost;
+} srbm_mpc_info;
+
+/* constants the reference reads from pinocchio at construction: mpc/models/model.cpp:27 (mass),
+ * mpc/models/single_rigid_body_model.cpp:33-37 (Ir), :258-308 (hip joint origins, trunk frame, FL FR RL RR) */
+typedef struct srbm_model {
+    double mass;
+    double Ir[9];
+    double hip_xy[8];
+} srbm_model;
+
+/* MPCSingleRigidBody::MPCSingleRigidBody x batch  (mpc/mpc_single_rigid_body.cpp:9-23, mpc/mpc.cpp:38-76) */
+int srbm_batch_create(srbm_batch** out, int batch, const srbm_mpc_info* info, const srbm_model* model, int device);
+int srbm_batch_destroy(srbm_batch* h);
+const char* srbm_last_error(void);
+
+/* MPC::AddQuadraticTrackingCost (mpc/mpc.cpp:533-540): Q 12x12 row-major, state_des in tangent coordinates (12) */
+int srbm_add_quadratic_tracking_cost(srbm_batch* h, const double* state_des12, const double* Q144);
+/* MPC::SetQuadraticFinalCost / SetLinearFinalCost (mpc/mpc.cpp:137-151) */
+int srbm_set_quadratic_final_cost(srbm_batch* h, const double* Phi144);
+int srbm_set_linear_final_cost(srbm_batch* h, const double* w12);
+/* MPC::SetStateTrajectoryWarmStart (mpc/mpc.cpp:700-706): states[batch][13], replicated over the horizon */
+int srbm_set_state_trajectory_warm_start(srbm_batch* h, const double* states);
+/* ClarabelInterface tolerances (mpc/qp/clarabel_interface.cpp:18-27,165-175) for the on-device IPM */
+int srbm_set_solver_tolerances(srbm_batch* h, double tol_gap_abs, double tol_gap_rel, double tol_feas, int max_iter);
+
+/* MPC::CreateInitialRun (mpc/mpc.cpp:78-90): 10 solves at t = 0.   state[batch][13], ee[batch][4][3] */
+int srbm_create_initial_run(srbm_batch* h, const double* state, const double* ee_start_locations);
+/* MPC::GetRealTimeUpdate (mpc/mpc.cpp:92-108) == one MPCSingleRigidBody::Solve (mpc_single_rigid_body.cpp:25-216).
+ * init_time[batch] */
+int srbm_get_real_time_update(srbm_batch* h, const double* state, const double* init_time, const double* ee_start_locations);
+/* same, inputs already resident in HBM (device pointers), asynchronous on the handle's stream */
+int srbm_get_real_time_update_dev(srbm_batch* h, const double* state_dev, const double* init_time_dev, const double* ee_dev);
+/* Device-resident open-loop protocol of test/gait_opt_playground.cpp:113-126: `steps` RTI iterations with
+ * state := node 1 of the previous trajectory, foot locations := previous trajectory at t, t_i = (first_index+i)*dt.
+ * No host round trip between iterations.  Asynchronous; srbm_synchronize() to wait. */
+int srbm_rti_advance(srbm_batch* h, int first_index, int steps);
+int srbm_synchronize(srbm_batch* h);
+void* srbm_stream(srbm_batch* h);            /* hipStream_t the kernels are launched on */
+
+/* MPC::UpdateContactTimes (mpc/mpc.cpp:1085-1088): times[batch][4][max_contacts], counts must match the current
+ * number of contact knots of every foot */
+int srbm_update_contact_times(srbm_batch* h, const double* times, int max_contacts);
+
+/* ---- results (all copied to host) ---- */
+/* sizes[batch][8] = n, m, n_eq, n_ineq, n_force_vars, n_pos_vars, n_td_rows, n_force_samples */
+int srbm_get_sizes(srbm_batch* h, int* sizes);
+/* status[batch] = mpc::SolveQuality (mpc/include/qp/qp_interface.h:12-22); err[batch] = error bits (0 = none) */
+int srbm_get_status(srbm_batch* h, int* status, int* err);
+/* stats[batch][8] = alpha, cost (GetCost), L1 dynamics defect, step norm, qp iterations, res_primal, res_dual, gap_rel */
+int srbm_get_stats(srbm_batch* h, double* stats);
+/* MPC::GetQPSolution (prev_qp_sol after the line search), x[batch][ld]; ld >= n_max */
+int srbm_get_qp_solution(srbm_batch* h, double* x, int ld);
+int srbm_get_raw_qp_minimiser(srbm_batch* h, double* x, int ld);
+/* ClarabelInterface::GetDualSolution in the reference's row order; z[batch][ld] */
+int srbm_get_dual_solution(srbm_batch* h, double* z, double* s, int ld);
+/* Trajectory::GetStates, states[batch][N+1][13] */
+int srbm_get_trajectory_states(srbm_batch* h, double* states);
+/* knot tables of one instance: times[4][32], kinds[4][32] (0 LO, 1 TD, 2 stance-interior, 3 mid-swing), nk[4],
+ * fvals[4][3][32][2], pvals[4][2][32], box[2] */
+int srbm_get_knots(srbm_batch* h, int inst, double* times, int* kinds, int* nk, double* fvals, double* pvals, double* box);
+/* Dense expansion of the structured QP of the LAST solve of one instance into the reference's layout
+ * (rows/cols as SURVEY.md Appendix A): A[m][n], b[m], P[n][n], q[n].  Debug / parity-test aid. */
+int srbm_export_qp(srbm_batch* h, int inst, double* A, double* b, double* P, double* q);
+/* bytes of HBM held per instance (persistent record + per-solve workspace) */
+long srbm_bytes_per_instance(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
