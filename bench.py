@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MPC RTI iterations / second, batched A1 SRBM, N=20 (BASELINE.json `metric`, config[1]).
+
+Workload (Config B): 256 independent MPC instances PER GPU, horizon N=20, dt=0.05,
+apps/a1_configuration.yaml values, synthetic initial states (std::mt19937_64-style seeds 20240112+b, here numpy MT19937).
+Protocol: 10 cold-start solves per instance (MPC::CreateInitialRun, untimed set-up), W warm-up RTI steps, then K timed
+RTI steps with t_i = i*dt and state := node 1 of the previous trajectory (test/gait_opt_playground.cpp:113-126), run
+device-resident (inputs are in HBM when the timed region starts).  One "step" = one RTI iteration of every instance
+of the batch (shift -> assemble -> condense -> QP solve -> line search -> trajectory update).
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); instances are sharded over ranks (weak
+scaling: 256 per GPU) with no data-path collective; one all-gather of the per-instance result records closes the timed
+region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (public spec; the CDNA guide lists no fp64 row)
+BATCH_PER_GPU = 256
+RESULT_LD = 8 + 21 * 12 + 160
+
+
+# ---------- helpers shared with the CPU (gloo) test of the sharding logic ----------
+def shard_range(total, rank, world):
+    """contiguous block [lo, hi) of `total` instances owned by `rank`"""
+    per = total // world
+    rem = total % world
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)
+
+
+def gather_records(rec, world):
+    """all-gather of fixed-size per-instance result records (rows) over the ranks"""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return rec
+    out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
+    dist.all_gather_into_tensor(out, rec.contiguous())
+    return out
+
+
+def max_over_ranks(value):
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return value
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def config_b_instance(cfg, b):
+    """instance b of Config B: perturbed initial state + foot positions"""
+    rng = np.random.Generator(np.random.MT19937(20240112 + b))
+    u = lambda lo, hi: lo + (hi - lo) * rng.random()
+    m = cfg['mass']
+    p = np.array([u(-0.02, 0.02), u(-0.02, 0.02), 0.30 + u(-0.01, 0.01)])
+    v = np.array([u(-0.5, 0.5), u(-0.5, 0.5), u(-0.1, 0.1)])
+    rpy = np.array([u(-0.05, 0.05), u(-0.05, 0.05), u(-0.05, 0.05)])
+    L = np.array([u(-0.1, 0.1), u(-0.1, 0.1), u(-0.1, 0.1)])
+    th = np.linalg.norm(rpy)
+    quat = np.concatenate([np.sin(th / 2) / th * rpy, [np.cos(th / 2)]])
+    state = np.concatenate([p, m * v, quat, L])
+    hips = np.array([[0.2055, 0.147], [0.2055, -0.147], [-0.1555, 0.147], [-0.1555, -0.147]])
+    ee = np.zeros((4, 3))
+    for e in range(4):
+        ee[e, 0] = p[0] + hips[e, 0] + u(-0.02, 0.02)
+        ee[e, 1] = p[1] + hips[e, 1] + u(-0.02, 0.02)
+    return state, ee
+
+
+def cpu_baseline(cfg, seconds_budget=20.0):
+    """The oracle (CPU restatement of the reference algorithm, oracle/) timed on this box's host cores: a bounded sample
+    of the SAME workload -- instances 0.. of Config B, 10 cold-start solves each (untimed) then 30 timed RTI steps --
+    single thread.  Reported beside the GPU number; it is not the target."""
+    from oracle_py import OracleMPC, build_oracle
+    build_oracle()
+    dt = cfg['integrator_dt']
+    done, el, inst = 0, 0.0, 0
+    while el < seconds_budget and inst < 64:
+        s0, ee = config_b_instance(cfg, inst)
+        o = OracleMPC(cfg)
+        o.set_warmstart(s0)
+        o.initial_run(s0, ee)
+        state = s0
+        t0 = time.perf_counter()
+        for i in range(30):
+            t = i * dt
+            eel = np.array([[o.ee_value(e, 1, c, t) for c in range(3)] for e in range(4)])
+            o.rti(state, t, eel)
+            state = o.states()[1]
+        el += time.perf_counter() - t0
+        done += 30
+        inst += 1
+    return {'value': done / el, 'unit': 'it/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d Config-B instances x 30 RTI steps after 10 cold-start solves each, oracle/ (C++ -O2, 1 thread)' % inst}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='instances per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from srbm_loader import host
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    cfg = host.load_config('a1_configuration')
+    B = args.batch
+    lo, hi = shard_range(B * world, rank, world)            # this rank's instances of the global batch
+    states, ees = zip(*[config_b_instance(cfg, b) for b in range(lo, hi)])
+    states, ees = np.array(states), np.array(ees).reshape(hi - lo, 12)
+
+    mpc = host.BatchMPC(cfg, hi - lo, device=local_rank)
+    mpc.set_state_trajectory_warm_start(states)
+    mpc.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+    mpc.create_initial_run(states, ees)                       # 10 cold-start solves (set-up, untimed)
+    mpc.rti_advance(0, args.warmup)
+    mpc.synchronize()
+    rec = torch.zeros((hi - lo, RESULT_LD), dtype=torch.float64, device='cuda')
+
+    it0, fl0 = mpc.work_counters()
+    mpc.enable_kernel_timing(args.steps)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mpc.rti_advance(args.warmup, args.steps)                  # K device-resident RTI steps
+    mpc.pack_results_dev(rec.data_ptr(), RESULT_LD)
+    mpc.synchronize()
+    allrec = gather_records(rec, world)                        # RCCL all-gather of the solved trajectories
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+
+    k3_ms, k3_launches = mpc.kernel_timing()
+    it1, fl1 = mpc.work_counters()
+    st, err = mpc.status()
+    ok = bool(np.all(err == 0) and np.all((st == 0) | (st == 1) | (st == 2)))
+    n_inst = B * world
+    value = n_inst * args.steps / elapsed
+
+    if rank == 0:
+        status_all = allrec[:, 0].cpu().numpy()
+        k3_avg_s = (k3_ms / max(1, k3_launches)) * 1e-3
+        flops_per_launch = (fl1 - fl0) / max(1, k3_launches)
+        achieved = flops_per_launch / k3_avg_s / 1e12 if k3_avg_s > 0 else 0.0
+        out = {
+            'metric': 'MPC RTI iterations/sec (batched A1 SRBM, N=20)',
+            'value': value, 'unit': 'it/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'Config B: %d A1 SRBM MPC instances per GPU, N=20, dt=0.05, a1_configuration.yaml values, '
+                                   '10 cold-start solves then open-loop RTI steps (state := node 1)' % B,
+                       'batch_per_gpu': B, 'global_batch': n_inst, 'num_nodes': 20, 'parallelism': 'instances sharded x%d' % world,
+                       'all_solved': ok, 'statuses': {int(k): int(v) for k, v in zip(*np.unique(status_all, return_counts=True))},
+                       'mean_ipm_iterations': (it1 - it0) / max(1, (hi - lo) * args.steps)},
+            'roofline': {'bound': 'mfma', 'kernel': 'srbm_k3_ipm', 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': None,
+                         'avg_launch_ms': k3_avg_s * 1e3, 'algorithmic_flops_per_launch': flops_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

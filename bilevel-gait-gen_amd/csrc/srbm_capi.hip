@@ -24,7 +24,20 @@ struct srbm_batch {
     hipStream_t stream = nullptr;
     size_t k3_lds = 0;
     bool params_dirty = true;
+    // optional HIP-event timing of the dominant kernel (srbm_k3_ipm) on the launch stream
+    bool timing = false;
+    std::vector<hipEvent_t> ev_start, ev_stop;
+    size_t ev_used = 0;
 };
+
+__global__ void srbm_k_pack_results(const SrbmParams* __restrict__ Pp, const SrbmInst* __restrict__ insts, const SrbmWork* __restrict__ works,
+                                    double* __restrict__ out, int ld) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const SrbmInst& I = insts[b];
+    double* o = out + (size_t)b * ld;
+    if (tid == 0) { o[0] = I.status; o[1] = I.n; o[2] = I.m; o[3] = I.cost; o[4] = I.alpha; o[5] = I.err; o[6] = I.qp_iters; o[7] = I.init_time; }
+    for (int i = tid; i < I.n && 8 + i < ld; i += blockDim.x) o[8 + i] = works[b].x[i];
+}
 
 // ---------------- small device kernels of the host protocol ----------------
 
@@ -70,7 +83,7 @@ __global__ void srbm_k_init(const SrbmParams* __restrict__ Pp, SrbmInst* __restr
     I.box[0] = Pp->box0[0]; I.box[1] = Pp->box0[1];
     I.init_time = 0; I.alpha = 0; I.cost = 0; I.eq_violation = 0; I.step_norm = 0; I.qp_cost = 0; I.res_primal = 0; I.res_dual = 0; I.gap = 0;
     I.status = SRBM_UNSOLVED; I.qp_iters = 0; I.n = 0; I.m = 0; I.n_eq = 0; I.n_ineq = 0; I.nfv = 0; I.npv = 0; I.n_td = 0; I.n_samples = 0;
-    I.err = 0; I.run_num = 0;
+    I.err = 0; I.run_num = 0; I.acc_iters = 0; I.acc_flops = 0;
 }
 
 __global__ void srbm_k_warm_start(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, const double* __restrict__ states) {
@@ -144,7 +157,10 @@ static int launch_step(srbm_batch* h) {
     const int B = h->batch;
     hipLaunchKernelGGL(srbm_k1_assemble, dim3(B), dim3(K1_THREADS), 0, h->stream, h->dp, h->insts, h->works, h->d_state, h->d_time, h->d_ee);
     hipLaunchKernelGGL(srbm_k2_condense, dim3(B), dim3(K2_THREADS), 0, h->stream, h->dp, h->insts, h->works);
+    const bool tm = h->timing && h->ev_used < h->ev_start.size();
+    if (tm) HIPCHK(hipEventRecord(h->ev_start[h->ev_used], h->stream));
     hipLaunchKernelGGL(srbm_k3_ipm, dim3(B), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works);
+    if (tm) { HIPCHK(hipEventRecord(h->ev_stop[h->ev_used], h->stream)); h->ev_used++; }
     hipLaunchKernelGGL(srbm_k4_update, dim3(B), dim3(K4_THREADS), 0, h->stream, h->dp, h->insts, h->works);
     HIPCHK(hipGetLastError());
     return 0;
@@ -154,6 +170,14 @@ extern "C" {
 
 const char* srbm_last_error(void) { return g_err.c_str(); }
 long srbm_bytes_per_instance(void) { return (long)(sizeof(SrbmInst) + sizeof(SrbmWork)); }
+/* diagnostic builds (-DSRBM_PROFILE) only: cycles per IPM phase of one instance, 16 slots */
+int srbm_debug_get_profile(srbm_batch* h, int inst, double* out16) {
+    if (!h || inst < 0 || inst >= h->batch) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out16, reinterpret_cast<const char*>(h->works + inst) + offsetof(SrbmWork, prof), sizeof(double) * 16, hipMemcpyDeviceToHost));
+    return 0;
+}
 
 int srbm_batch_create(srbm_batch** out, int batch, const srbm_mpc_info* info, const srbm_model* model, int device) {
     if (!out || !info || !model || batch <= 0) return fail("srbm_batch_create: bad arguments");
@@ -315,6 +339,47 @@ int srbm_update_contact_times(srbm_batch* h, const double* times, int max_contac
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipFree(d));
+    return 0;
+}
+
+int srbm_enable_kernel_timing(srbm_batch* h, int max_launches) {
+    if (!h || max_launches < 0) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    while ((int)h->ev_start.size() < max_launches) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+        h->ev_start.push_back(a); h->ev_stop.push_back(b);
+    }
+    h->ev_used = 0; h->timing = max_launches > 0;
+    return 0;
+}
+int srbm_get_kernel_timing(srbm_batch* h, double* total_ms, int* launches) {
+    if (!h || !total_ms || !launches) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double tot = 0;
+    for (size_t i = 0; i < h->ev_used; i++) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, h->ev_start[i], h->ev_stop[i])); tot += ms; }
+    *total_ms = tot; *launches = (int)h->ev_used;
+    return 0;
+}
+int srbm_get_work_counters(srbm_batch* h, double* total_ipm_iterations, double* total_algorithmic_flops) {
+    if (!h) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<SrbmInst> v(h->batch);
+    HIPCHK(hipMemcpy(v.data(), h->insts, sizeof(SrbmInst) * (size_t)h->batch, hipMemcpyDeviceToHost));
+    double it = 0, fl = 0;
+    for (auto& I : v) { it += I.acc_iters; fl += I.acc_flops; }
+    if (total_ipm_iterations) *total_ipm_iterations = it;
+    if (total_algorithmic_flops) *total_algorithmic_flops = fl;
+    return 0;
+}
+int srbm_pack_results_dev(srbm_batch* h, double* out_dev, int ld) {
+    if (!h || !out_dev || ld < 8) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    hipLaunchKernelGGL(srbm_k_pack_results, dim3(h->batch), dim3(64), 0, h->stream, h->dp, h->insts, h->works, out_dev, ld);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

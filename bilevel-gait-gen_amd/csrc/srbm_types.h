@@ -55,6 +55,7 @@ typedef struct SrbmInst {
     int nk[SRBM_NEE];
     uint8_t kind[SRBM_NEE][SRBM_KMAX];
     int status, qp_iters, n, m, n_eq, n_ineq, nfv, npv, n_td, n_samples, err, run_num;
+    double acc_iters, acc_flops;                  /* running totals: IPM iterations, algorithmic flops (SURVEY.md 8d formula) */
 } SrbmInst;
 
 /* per (node, foot) linearisation record */
@@ -105,4 +106,5 @@ typedef struct SrbmWork {
     double x[SRBM_NXMAX];                         /* prev_qp_sol after the line search */
     double z[SRBM_MMAX];                          /* dual vector in the reference's row order */
     double s[SRBM_MMAX];
+    double prof[16];                              /* diagnostic builds only (-DSRBM_PROFILE): cycles per IPM phase */
 } SrbmWork;

@@ -183,6 +183,23 @@ class BatchMPC:
         assert a.ndim == 3 and a.shape[0] == self.batch and a.shape[1] == 4
         self._chk(self.L.srbm_update_contact_times(self.h, _d(a), a.shape[2]))
 
+    # ---- measurement aids ----
+    def enable_kernel_timing(self, max_launches):
+        self._chk(self.L.srbm_enable_kernel_timing(self.h, int(max_launches)))
+
+    def kernel_timing(self):
+        ms = C.c_double(0); n = C.c_int(0)
+        self._chk(self.L.srbm_get_kernel_timing(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def work_counters(self):
+        it = C.c_double(0); fl = C.c_double(0)
+        self._chk(self.L.srbm_get_work_counters(self.h, C.byref(it), C.byref(fl)))
+        return it.value, fl.value
+
+    def pack_results_dev(self, ptr, ld):
+        self._chk(self.L.srbm_pack_results_dev(self.h, C.c_void_p(ptr), int(ld)))
+
     # ---- results ----
     def sizes(self):
         a = np.zeros((self.batch, 8), np.int32)

@@ -84,6 +84,14 @@ int srbm_get_knots(srbm_batch* h, int inst, double* times, int* kinds, int* nk, 
 /* Dense expansion of the structured QP of the LAST solve of one instance into the reference's layout
  * (rows/cols as SURVEY.md Appendix A): A[m][n], b[m], P[n][n], q[n].  Debug / parity-test aid. */
 int srbm_export_qp(srbm_batch* h, int inst, double* A, double* b, double* P, double* q);
+/* result records for collection across GPUs (one RCCL all-gather in bench.py): out_dev[batch][ld] on the handle's
+ * stream = {status, n, m, cost, alpha, err, qp_iters, init_time, x[0..n)} ; ld >= 8 */
+int srbm_pack_results_dev(srbm_batch* h, double* out_dev, int ld);
+/* measurement aids: HIP-event timing of the dominant kernel (srbm_k3_ipm) on the launch stream, and running totals
+ * of executed IPM iterations / algorithmic flops (SURVEY.md section 8d formula) summed over the batch */
+int srbm_enable_kernel_timing(srbm_batch* h, int max_launches);
+int srbm_get_kernel_timing(srbm_batch* h, double* total_ms, int* launches);
+int srbm_get_work_counters(srbm_batch* h, double* total_ipm_iterations, double* total_algorithmic_flops);
 /* bytes of HBM held per instance (persistent record + per-solve workspace) */
 long srbm_bytes_per_instance(void);
 

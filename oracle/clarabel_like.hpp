@@ -221,6 +221,10 @@ public:
             double dtau, dkap;
             solve_step(cx, cz, (1 - sigma) * rtau, kappa_ * tau_ + dkap_a * dtau_a - sigma * mu, dx, dz, ds, dtau, dkap);
             double alpha = step_length(dz, ds, dtau, dkap, 1.0) * S.max_step_fraction;
+            bool finite_step = std::isfinite(alpha) && std::isfinite(dtau) && std::isfinite(dkap);
+            for (int i = 0; i < n && finite_step; i++) finite_step = std::isfinite(dx[i]);
+            for (int i = 0; i < m && finite_step; i++) finite_step = std::isfinite(dz[i]) && std::isfinite(ds[i]);
+            if (!finite_step) alpha = 0;   // Clarabel: NumericalError -> keep the iterate, post-process with reduced tolerances
             if (alpha < S.min_terminate_step_length) {
                 // Clarabel: step too small -> InsufficientProgress -> post-processed with the reduced tolerances
                 status = check(S.reduced_tol_gap_abs, S.reduced_tol_gap_rel, S.reduced_tol_feas, S.reduced_tol_infeas_abs,

@@ -1,0 +1,21 @@
+"""Diagnostic: per-phase cycle shares of the IPM kernel (build with -DSRBM_PROFILE; never quote its run time)."""
+import importlib.util, os, sys, ctypes as C
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location('srbm_host', os.path.join(ROOT, 'bilevel-gait-gen_amd', 'host.py'))
+host = importlib.util.module_from_spec(spec); spec.loader.exec_module(host)
+host.LIB_PATH = os.path.join(ROOT, 'bilevel-gait-gen_amd', 'libsrbm_rti_prof.so')
+cfg = host.load_config(sys.argv[1] if len(sys.argv) > 1 else 'a1_configuration')
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+s0 = np.array(cfg['srb_init'], float)
+ee = np.array([[0.2, 0.2, 0], [0.2, -0.2, 0], [-0.2, 0.2, 0], [-0.2, -0.2, 0]], float)
+gb = host.BatchMPC(cfg, B); gb.set_state_trajectory_warm_start(s0); gb.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+gb.create_initial_run(s0, ee)
+gb.rti_advance(0, 4); gb.synchronize()
+out = np.zeros(16)
+gb.L.srbm_debug_get_profile(gb.h, 0, out.ctypes.data_as(C.POINTER(C.c_double)))
+names = ['misc/loop', 'H->LDS', 'row residuals', "G'lam", 'Hu+term', 'M sparse', 'M dense SYR2K', 'Cholesky', "aff rhs G'v", 'trisolve aff', 'steplen+corr rhs', 'trisolve corr', 'step update']
+tot = out.sum()
+print('iters', gb.stats()[0, 4], 'total stamp ticks %.0f' % tot)
+for n, v in zip(names, out):
+    print('%-18s %10.0f  %5.1f%%' % (n, v, 100 * v / tot))

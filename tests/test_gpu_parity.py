@@ -1,0 +1,265 @@
+"""GPU parity tests: the HIP path (through the C-ABI of include/srbm_rti.h) against the CPU oracle on identical inputs.
+
+Tolerances (BASELINE.json north_star / BASELINE.md section 3.5):
+  * integer artefacts -- QP sizes, row counts, knot kinds/counts, status codes -- bit-exact;
+  * knot times (contact schedule) -- bit-exact (same IEEE operations in the same order);
+  * assembled QP coefficients (first solve, identical linearisation point) -- <= 1e-12 absolute;
+  * primal solution / trajectory -- <= 1e-4 relative:  max|x_gpu - x_cpu| / max(1, max|x_cpu|).
+"""
+import numpy as np
+import pytest
+
+from oracle_py import OracleMPC, load_config
+from srbm_loader import host
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4          # stated tolerance of the north star
+EE0 = np.array([[0.2, 0.2, 0], [0.2, -0.2, 0], [-0.2, 0.2, 0], [-0.2, -0.2, 0]], float)   # test/simulation_mpc.cpp:104-108
+EE_TEST = np.array([[0.1526, 0.12523, 0.011089], [0.1526, -0.12523, 0.011089],
+                    [-0.208321844, 0.1363286, 0.01444], [-0.208321844, -0.1363286, 0.01444]])  # test/mpc_test.cpp:97-101
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+def make_pair(cfg, batch=2, state=None):
+    s0 = np.array(cfg['srb_init'], float) if state is None else state
+    g = host.BatchMPC(cfg, batch)
+    g.set_state_trajectory_warm_start(s0)
+    g.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+    o = OracleMPC(cfg)
+    o.set_warmstart(s0)
+    return g, o, s0
+
+
+def check_knots(g, o, inst=0):
+    kg = g.knots(inst)
+    kind_of = {}
+    for ee in range(4):
+        ko = o.knots(ee)
+        K = ko['K']
+        assert kg['nk'][ee] == K
+        # knot times: bit-exact
+        assert np.array_equal(kg['times'][ee, :K], ko['times']), (ee, kg['times'][ee, :K] - ko['times'])
+        # knot kinds vs (TimeType, force NodeType): LO=0, TD=1, stance-interior=2 (Inter + FullDeriv), mid-swing=3 (Inter + Empty)
+        for k in range(K):
+            tt, ft = int(ko['ttypes'][k]), int(ko['ftype'][0][k])
+            expect = tt if tt < 2 else (2 if ft == 1 else 3)
+            assert kg['kinds'][ee, k] == expect, (ee, k)
+
+
+def test_first_solve_structured_qp_expands_to_reference_qp():
+    cfg = load_config()
+    g, o, s0 = make_pair(cfg)
+    g.get_real_time_update(s0, 0.0, EE_TEST)
+    o.rti(s0, 0.0, EE_TEST)
+    sz, osz = g.sizes()[0], o.sizes()
+    assert (sz[0], sz[1], sz[2], sz[3], sz[4], sz[5], sz[6]) == (osz['n'], osz['m'], osz['n_eq'], osz['n_ineq'], osz['n_force'], osz['n_pos'], osz['n_td'])
+    assert (sz[0], sz[1]) == (372, 1012)
+    A, b, P, q = g.export_qp(0)
+    Ao, bo, Po, qo = o.qp_dense()
+    assert np.array_equal(A != 0, Ao != 0)                # sparsity pattern: exact
+    assert np.abs(A - Ao).max() <= 1e-12
+    assert np.abs(b - bo).max() <= 1e-12
+    assert np.abs(P - Po).max() <= 1e-12 and np.abs(q - qo).max() <= 1e-12
+    check_knots(g, o)
+    st, err = g.status()
+    assert err[0] == 0 and st[0] == o.stats()['status'] == 0
+    n, m = osz['n'], osz['m']
+    assert relerr(g.raw_qp_minimiser()[0, :n], o.qp_x()) < REL_TOL
+    assert relerr(g.qp_solution()[0, :n], o.x()) < REL_TOL
+    # KKT of the reference QP holds for the GPU primal/dual pair (duals of all-zero rows are not unique: skip them)
+    x = g.raw_qp_minimiser()[0, :n]
+    z, s = g.dual_solution()
+    z, s = z[0, :m], s[0, :m]
+    assert np.abs(Ao @ x + s - bo).max() < 1e-7
+    assert np.abs(Po @ x + qo + Ao.T @ z).max() / max(1.0, np.abs(qo).max()) < 1e-7
+    nzrow = np.abs(Ao).sum(axis=1) > 0
+    zo = o.z()
+    scale = max(1.0, np.abs(zo[nzrow]).max())
+    assert np.abs(z[nzrow] - zo[nzrow]).max() / scale < 1e-4
+
+
+@pytest.mark.parametrize('cfgname,nsteps', [('a1_configuration', 14), ('a1_config_distr_rejection', 6)])
+def test_cold_start_and_open_loop_rti_parity(cfgname, nsteps):
+    """CreateInitialRun (mpc.cpp:78-90) + the open-loop protocol of test/gait_opt_playground.cpp:113-126; both sides get
+    the same measured state / foot positions each step (taken from the oracle trajectory)."""
+    cfg = load_config(cfgname)
+    g, o, s0 = make_pair(cfg)
+    g.create_initial_run(s0, EE0)
+    o.initial_run(s0, EE0)
+    dt = cfg['integrator_dt']
+    seen = set()
+    for i in range(nsteps):
+        t = i * dt
+        state = o.states()[1] if i > 0 else s0
+        ee = np.array([[o.ee_value(e, 1, c, t) for c in range(3)] for e in range(4)])
+        g.get_real_time_update(state, t, ee)
+        so = o.rti(state, t, ee)
+        sz, osz = g.sizes()[0], o.sizes()
+        assert (sz[0], sz[1], sz[2], sz[3], sz[6]) == (osz['n'], osz['m'], osz['n_eq'], osz['n_ineq'], osz['n_td']), i
+        seen.add((int(sz[0]), int(sz[1])))
+        st, err = g.status()
+        assert err[0] == 0, (i, err[0])
+        assert st[0] == so, (i, st[0], so)            # status codes: exact
+        check_knots(g, o)                              # contact schedule: bit-exact
+        n = osz['n']
+        assert relerr(g.qp_solution()[0, :n], o.x()) < REL_TOL, i
+        assert relerr(g.trajectory_states()[0], o.states()) < REL_TOL, i
+        gs, os_ = g.stats()[0], o.stats()
+        if os_['step_norm'] > 1e-3:                    # the Armijo test is noise below that (merit differences ~1e-12)
+            assert gs[0] == os_['alpha'], i
+        assert abs(gs[1] - os_['cost']) <= 1e-6 * max(1.0, abs(os_['cost'])), i
+        assert np.array_equal(g.knots(0)['box'], np.array(os_['box'])), i
+    if cfgname == 'a1_configuration':
+        assert len(seen) >= 3        # sizes are ragged in time (phases enter / leave the horizon)
+
+
+def config_b_instance(cfg, b):
+    """Synthetic instance b of Config B: perturbed initial state and foot positions."""
+    rng = np.random.Generator(np.random.MT19937(20240112 + b))
+    u = lambda lo, hi: lo + (hi - lo) * rng.random()
+    m = cfg['mass']
+    p = np.array([u(-0.02, 0.02), u(-0.02, 0.02), 0.30 + u(-0.01, 0.01)])
+    v = np.array([u(-0.5, 0.5), u(-0.5, 0.5), u(-0.1, 0.1)])
+    rpy = np.array([u(-0.05, 0.05), u(-0.05, 0.05), u(-0.05, 0.05)])
+    L = np.array([u(-0.1, 0.1), u(-0.1, 0.1), u(-0.1, 0.1)])
+    th = np.linalg.norm(rpy)
+    quat = np.concatenate([np.sin(th / 2) / th * rpy, [np.cos(th / 2)]])
+    state = np.concatenate([p, m * v, quat, L])
+    hips = np.array([[0.2055, 0.147], [0.2055, -0.147], [-0.1555, 0.147], [-0.1555, -0.147]])
+    ee = np.zeros((4, 3))
+    for e in range(4):
+        ee[e, 0] = p[0] + hips[e, 0] + u(-0.02, 0.02)
+        ee[e, 1] = p[1] + hips[e, 1] + u(-0.02, 0.02)
+    return state, ee
+
+
+def test_batch_of_distinct_instances_matches_per_instance_oracle():
+    cfg = load_config()
+    B = 8
+    states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees)
+    g = host.BatchMPC(cfg, B)
+    g.set_state_trajectory_warm_start(states)
+    g.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+    g.create_initial_run(states, ees.reshape(B, 12))
+    g.get_real_time_update(states, 0.0, ees.reshape(B, 12))
+    xs = g.qp_solution(); st, err = g.status(); sz = g.sizes(); tr = g.trajectory_states()
+    for b in range(B):
+        o = OracleMPC(cfg)
+        o.set_warmstart(states[b])
+        o.initial_run(states[b], ees[b])
+        so = o.rti(states[b], 0.0, ees[b])
+        n = o.sizes()['n']
+        assert sz[b, 0] == n and sz[b, 1] == o.sizes()['m']
+        assert st[b] == so and err[b] == 0
+        assert relerr(xs[b, :n], o.x()) < REL_TOL, b
+        assert relerr(tr[b], o.states()) < REL_TOL, b
+
+
+def test_device_resident_protocol_equals_host_driven_loop():
+    cfg = load_config()
+    s0 = np.array(cfg['srb_init'], float)
+    B = 3
+    ga = host.BatchMPC(cfg, B); ga.set_state_trajectory_warm_start(s0); ga.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+    gb = host.BatchMPC(cfg, B); gb.set_state_trajectory_warm_start(s0); gb.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+    ga.create_initial_run(s0, EE0); gb.create_initial_run(s0, EE0)
+    o = OracleMPC(cfg); o.set_warmstart(s0); o.initial_run(s0, EE0)
+    K = 7
+    ga.rti_advance(0, K); ga.synchronize()
+    dt = cfg['integrator_dt']
+    for i in range(K):
+        t = i * dt
+        tr = gb.trajectory_states()
+        # foot positions of the previous trajectory at t: evaluate through the oracle API on the oracle's own (parity-checked) trajectory
+        ee = np.array([[o.ee_value(e, 1, c, t) for c in range(3)] for e in range(4)])
+        gb.get_real_time_update(tr[:, 1, :], t, ee)
+        o.rti(o.states()[1], t, ee)
+    xa, xb = ga.qp_solution(), gb.qp_solution()
+    n = int(ga.sizes()[0, 0])
+    assert np.array_equal(ga.sizes(), gb.sizes())
+    assert relerr(xa[:, :n], xb[:, :n]) < 1e-5
+    assert relerr(xa[0, :n], o.x()) < REL_TOL
+
+
+def test_updated_contact_times_parity():
+    """MPC::UpdateContactTimes (mpc.cpp:1085-1088 -> EndEffectorSplines::SetContactTimes :860-892) then an RTI step."""
+    cfg = load_config()
+    g, o, s0 = make_pair(cfg)
+    g.create_initial_run(s0, EE0); o.initial_run(s0, EE0)
+    ct = [o.contact_times(e)[0] for e in range(4)]
+    new = [c.copy() for c in ct]
+    new[0][1] += 0.03; new[0][2] += 0.01; new[3][2] -= 0.02; new[1][1] += 0.015
+    o.set_contact_times(new)
+    arr = np.zeros((2, 4, 8))
+    for e in range(4):
+        arr[:, e, :len(new[e])] = new[e]
+    g.update_contact_times(arr)
+    check_knots(g, o)
+    g.get_real_time_update(s0, 0.0, EE0)
+    so = o.rti(s0, 0.0, EE0)
+    st, err = g.status()
+    assert err[0] == 0 and st[0] == so
+    n = o.sizes()['n']
+    assert (g.sizes()[0, 0], g.sizes()[0, 1]) == (n, o.sizes()['m'])
+    check_knots(g, o)
+    assert relerr(g.qp_solution()[0, :n], o.x()) < REL_TOL
+
+
+def test_short_horizon_config_a():
+    cfg = load_config(num_nodes=10)       # Config A of BASELINE.json: N=10 plumbing case
+    g, o, s0 = make_pair(cfg)
+    g.create_initial_run(s0, EE0); o.initial_run(s0, EE0)
+    g.get_real_time_update(s0, 0.0, EE0); so = o.rti(s0, 0.0, EE0)
+    sz = g.sizes()[0]
+    assert (sz[0], sz[1]) == (o.sizes()['n'], o.sizes()['m']) == (252, 732)
+    assert g.status()[0][0] == so
+    assert relerr(g.qp_solution()[0, :252], o.x()) < REL_TOL
+
+
+def test_full_batch_properties():
+    """Size-independent properties at the bench batch (256): identical instances give bit-identical results,
+    a result does not depend on the instance's slot in the batch, dynamics rows of the QP hold for the QP minimiser."""
+    cfg = load_config()
+    B = 256
+    states, ees = zip(*[config_b_instance(cfg, b % 16) for b in range(B)])      # 16 distinct problems, 16 copies each
+    states, ees = np.array(states), np.array(ees).reshape(B, 12)
+    g = host.BatchMPC(cfg, B)
+    g.set_state_trajectory_warm_start(states)
+    g.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+    g.create_initial_run(states, ees)
+    g.rti_advance(0, 3); g.synchronize()
+    x = g.qp_solution(); st, err = g.status(); sz = g.sizes()
+    assert np.all(err == 0) and np.all(st == 0)
+    for b in range(16, B):
+        assert np.array_equal(x[b], x[b % 16]), b
+        assert np.array_equal(sz[b], sz[b % 16])
+    # dynamics rows: x_{k+1} = Abar x_k + Bbar u + c holds exactly for the raw minimiser (rollout) -> check through the exported QP
+    A, bvec, P, q = g.export_qp(5)
+    n = int(sz[5, 0])
+    xr = g.raw_qp_minimiser()[5, :n]
+    nx = (cfg['num_nodes'] + 1) * 12
+    assert np.abs(A[:nx] @ xr - bvec[:nx]).max() < 1e-9
+    zz, ss = g.dual_solution()
+    m = int(sz[5, 1])
+    assert ss[5, nx:m].min() > -1e-9 and zz[5, nx:nx + int(sz[5, 3])].min() > -1e-9
+
+
+def test_capacity_overflow_fails_loudly():
+    """More spline variables than the kernel's LDS budget (160) must raise an error bit, never a silent wrong answer."""
+    cfg = load_config()
+    g, o, s0 = make_pair(cfg)
+    g.create_initial_run(s0, EE0)
+    # squeeze many short phases into the horizon: contact times 0.2 apart are legal for the reference (gait_optimizer.cpp:412)
+    kg = g.knots(0)
+    nct = [int(np.sum(kg['kinds'][e, :kg['nk'][e]] <= 1)) for e in range(4)]
+    arr = np.zeros((2, 4, 8))
+    for e in range(4):
+        arr[:, e, :nct[e]] = 0.05 * np.arange(nct[e])      # 50 ms phases -> horizon needs > 160 variables
+    g.update_contact_times(arr)
+    g.get_real_time_update(s0, 0.0, EE0)
+    st, err = g.status()
+    assert (err[0] & 16) != 0 and st[0] == 8
