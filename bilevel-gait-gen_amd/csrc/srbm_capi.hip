@@ -178,6 +178,13 @@ int srbm_debug_get_profile(srbm_batch* h, int inst, double* out16) {
     HIPCHK(hipMemcpy(out16, reinterpret_cast<const char*>(h->works + inst) + offsetof(SrbmWork, prof), sizeof(double) * 16, hipMemcpyDeviceToHost));
     return 0;
 }
+int srbm_debug_get_trace(srbm_batch* h, int inst, double* out256) {
+    if (!h || inst < 0 || inst >= h->batch) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out256, reinterpret_cast<const char*>(h->works + inst) + offsetof(SrbmWork, dbg), sizeof(double) * 384, hipMemcpyDeviceToHost));
+    return 0;
+}
 
 int srbm_batch_create(srbm_batch** out, int batch, const srbm_mpc_info* info, const srbm_model* model, int device) {
     if (!out || !info || !model || batch <= 0) return fail("srbm_batch_create: bad arguments");

@@ -106,5 +106,8 @@ typedef struct SrbmWork {
     double x[SRBM_NXMAX];                         /* prev_qp_sol after the line search */
     double z[SRBM_MMAX];                          /* dual vector in the reference's row order */
     double s[SRBM_MMAX];
+    double w0[SRBM_MIMAX];                        /* IPM: unit weight of the row/cost-scaled problem, e_r^2 / c (kernel 3 scratch) */
     double prof[16];                              /* diagnostic builds only (-DSRBM_PROFILE): cycles per IPM phase */
+    double dbg[4 * 64];
+    double dbg2[4 * 32];                          /* diagnostic builds only: worst refinement row (index, s, lambda, e2) */                           /* diagnostic builds only: per-iteration (mu, alpha_aff, alpha, gap_rel) */
 } SrbmWork;

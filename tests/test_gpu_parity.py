@@ -280,6 +280,52 @@ def test_full_batch_properties():
     assert ss[5, nx:m].min() > -1e-9 and zz[5, nx:nx + int(sz[5, 3])].min() > -1e-9
 
 
+def test_config_b_all_instances_against_oracle_fixture():
+    """All 256 seeded instances of Config B over the first RTI steps against tests/golden/config_b_rti.json (the ORACLE's
+    results, written by oracle/tools/make_config_b_golden.py; tests/test_oracle_mpc.py re-derives a sample of it on CPU).
+    Status classes must agree instance by instance -- solved {Solved, SolvedInacc}, primal infeasible {3, 5} -- the
+    Armijo step length must be identical, and the QP minimiser must agree to REL_TOL.  An instance leaves the comparison
+    once either side reports a QP that was not solved: the reference then continues from a solver-specific vector
+    (Clarabel's infeasibility certificate / last iterate), which no other solver reproduces."""
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'config_b_rti.json')))
+    cfg = load_config()
+    B = 256
+    states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees).reshape(B, 12)
+    g = host.BatchMPC(cfg, B)
+    g.set_state_trajectory_warm_start(states)
+    g.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+    g.create_initial_run(states, ees)
+    cls = lambda v: 'solved' if v <= 1 else ('infeasible' if v in (3, 5) else 'unconverged')
+    alive = np.ones(B, bool)
+    n_inf = 0
+    for i in range(gold['steps']):
+        g.rti_advance(i, 1); g.synchronize()
+        st, err = g.status(); stats = g.stats(); x = g.raw_qp_minimiser(); sz = g.sizes()
+        assert np.all(err == 0)
+        for b in range(B):
+            if not alive[b]:
+                continue
+            r = gold['instances'][b]['steps'][i]
+            co, cg = cls(r['status']), cls(int(st[b]))
+            if co == 'unconverged':          # the oracle hit max_iter / numerical trouble: nothing to compare against
+                alive[b] = False
+                continue
+            assert co == cg, (i, b, r['status'], int(st[b]))
+            if co == 'infeasible':
+                n_inf += 1
+                alive[b] = False
+                continue
+            assert (int(sz[b, 0]), int(sz[b, 1])) == (r['n'], r['m']), (i, b)
+            assert stats[b, 0] == r['alpha'], (i, b, stats[b, 0], r['alpha'])
+            scale = max(1.0, r['x_abs_max'])
+            assert np.abs(x[b, 12:24] - np.array(r['x_head'])).max() / scale < REL_TOL, (i, b)
+            assert abs(x[b, :r['n']].sum() - r['x_sum']) / (r['n'] * scale) < REL_TOL, (i, b)
+            assert stats[b, 4] <= 60, (i, b, stats[b, 4])       # no crawling: launch time is the slowest instance's
+    assert n_inf >= 4 and alive.sum() >= 240     # the seeded batch does contain infeasible cold starts; the rest stays in
+
+
 def test_capacity_overflow_fails_loudly():
     """More spline variables than the kernel's LDS budget (160) must raise an error bit, never a silent wrong answer."""
     cfg = load_config()

@@ -133,3 +133,20 @@ def test_contact_time_partials_match_finite_differences():
             assert np.abs(dG[:nfb] - fd_fb).max() < TOL, (ee, idx)
             fd_cone = (A2[ndyn + nfb:ndyn + nfb + ncone] - A1[ndyn + nfb:ndyn + nfb + ncone]) / dt
             assert np.abs(dG[nfb:nfb + ncone] - fd_cone).max() < TOL, (ee, idx)
+
+
+def test_config_b_fixture_is_reproducible_from_the_oracle():
+    """tests/golden/config_b_rti.json holds ORACLE outputs (not reference outputs: the reference cannot be built here,
+    SURVEY.md section 8c).  Re-derive a sample of it, including one primal-infeasible cold start."""
+    import json, os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle', 'tools'))
+    import make_config_b_golden as mk
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'config_b_rti.json')))
+    statuses = [r['steps'][0]['status'] for r in gold['instances']]
+    assert len(statuses) == 256 and statuses.count(3) >= 4
+    for b in (0, 11, statuses.index(3), 255):
+        got = mk.run(b)
+        ref = gold['instances'][b]
+        for a, r in zip(got['steps'], ref['steps']):
+            assert (a['status'], a['iters'], a['n'], a['m'], a['alpha']) == (r['status'], r['iters'], r['n'], r['m'], r['alpha'])
+            assert abs(a['x_sum'] - r['x_sum']) <= 1e-9 * max(1.0, abs(r['x_sum']))
