@@ -178,6 +178,38 @@ int srbm_debug_get_profile(srbm_batch* h, int inst, double* out16) {
     HIPCHK(hipMemcpy(out16, reinterpret_cast<const char*>(h->works + inst) + offsetof(SrbmWork, prof), sizeof(double) * 16, hipMemcpyDeviceToHost));
     return 0;
 }
+// unit-test hook for the dense building blocks: Cholesky of `count` packed lower-triangular n x n matrices, one workgroup each
+__global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_cholesky(int n, const double* __restrict__ Min, double* __restrict__ Lout, int* __restrict__ nreg_out) {
+    extern __shared__ double dbg_smem[];
+    const int np = n * (n + 1) / 2;
+    double* M = dbg_smem;
+    double* panel = dbg_smem + (size_t)SRBM_NUMAX * (SRBM_NUMAX + 1) / 2;
+    const double* src = Min + (size_t)blockIdx.x * np;
+    for (int e = threadIdx.x; e < np; e += DN_THREADS) M[e] = src[e];
+    __syncthreads();
+    DnTiles T;
+    int nreg = 0;
+    dn_load_packed(T, M, n);
+    dn_cholesky(T, M, n, panel, &nreg);
+    for (int e = threadIdx.x; e < np; e += DN_THREADS) Lout[(size_t)blockIdx.x * np + e] = M[e];
+    if (threadIdx.x == 0) nreg_out[blockIdx.x] = nreg;
+}
+int srbm_debug_cholesky(int n, int count, const double* M_packed, double* L_packed, int* nreg) {
+    if (n <= 0 || n > SRBM_NUMAX || count <= 0 || !M_packed || !L_packed || !nreg) return fail("bad arguments");
+    const size_t np = (size_t)n * (n + 1) / 2, bytes = np * count * sizeof(double);
+    double *dM = nullptr, *dL = nullptr; int* dr = nullptr;
+    HIPCHK(hipMalloc(&dM, bytes)); HIPCHK(hipMalloc(&dL, bytes)); HIPCHK(hipMalloc(&dr, sizeof(int) * count));
+    HIPCHK(hipMemcpy(dM, M_packed, bytes, hipMemcpyHostToDevice));
+    const size_t lds = ((size_t)SRBM_NUMAX * (SRBM_NUMAX + 1) / 2 + 2 * DN_PW * DN_TILE * DN_MAXT) * sizeof(double);
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k_debug_cholesky), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(srbm_k_debug_cholesky, dim3(count), dim3(DN_THREADS), lds, 0, n, dM, dL, dr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(L_packed, dL, bytes, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nreg, dr, sizeof(int) * count, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(dM)); HIPCHK(hipFree(dL)); HIPCHK(hipFree(dr));
+    return 0;
+}
 int srbm_debug_get_trace(srbm_batch* h, int inst, double* out256) {
     if (!h || inst < 0 || inst >= h->batch) return fail("bad arguments");
     HIPCHK(hipSetDevice(h->device));

@@ -14,7 +14,7 @@ gb.create_initial_run(s0, ee)
 gb.rti_advance(0, 4); gb.synchronize()
 out = np.zeros(16)
 gb.L.srbm_debug_get_profile(gb.h, 0, out.ctypes.data_as(C.POINTER(C.c_double)))
-names = ['misc/loop', 'H->LDS', 'row residuals', "G'lam", 'Hu+term', 'M sparse', 'M dense SYR2K', 'Cholesky', "aff rhs G'v", 'trisolve aff', 'steplen+corr rhs', 'trisolve corr', 'step update']
+names = ['misc/loop', 'H->LDS', 'row residuals', "G'lam", 'Hu+term', 'M sparse', 'M dense SYR2K', 'Cholesky', 'aff first solve', 'aff refine', 'corr first solve', 'corr refine', 'step update']
 tot = out.sum()
 print('iters', gb.stats()[0, 4], 'total stamp ticks %.0f' % tot)
 for n, v in zip(names, out):

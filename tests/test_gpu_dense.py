@@ -1,0 +1,70 @@
+"""GPU unit tests of the dense fp64 building blocks of the IPM kernel (bilevel-gait-gen_amd/csrc/srbm_dense.hiph) against
+numpy in fp64: the MFMA Cholesky of the register-resident normal matrix.  Tolerance: backward error |L L' - M| <=
+1e-13 |M| (fp64 Cholesky is backward stable; the entries of L themselves are compared to 1e-9 relative on
+well-conditioned inputs only)."""
+import ctypes as C
+import numpy as np
+import pytest
+
+from srbm_loader import host
+
+pytestmark = pytest.mark.gpu
+
+
+def pack(M):
+    n = M.shape[0]
+    return np.concatenate([M[i, :i + 1] for i in range(n)])
+
+
+def unpack(p, n):
+    L = np.zeros((n, n))
+    k = 0
+    for i in range(n):
+        L[i, :i + 1] = p[k:k + i + 1]; k += i + 1
+    return L
+
+
+def device_cholesky(mats):
+    lib = host.lib()
+    n = mats[0].shape[0]
+    inp = np.ascontiguousarray(np.stack([pack(M) for M in mats]))
+    out = np.zeros_like(inp); nreg = np.zeros(len(mats), np.int32)
+    rc = lib.srbm_debug_cholesky(n, len(mats), inp.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double)),
+                                 nreg.ctypes.data_as(C.POINTER(C.c_int)))
+    assert rc == 0, lib.srbm_last_error().decode()
+    return [unpack(o, n) for o in out], nreg
+
+
+@pytest.mark.parametrize('n', [1, 3, 4, 15, 16, 17, 63, 64, 118, 120, 157, 160])
+def test_mfma_cholesky_matches_numpy(n):
+    rng = np.random.default_rng(n)
+    mats = []
+    for _ in range(3):
+        A = rng.standard_normal((n, n + 5))
+        mats.append(A @ A.T + 0.1 * np.eye(n))
+    Ls, nreg = device_cholesky(mats)
+    assert np.all(nreg == 0)
+    for M, L in zip(mats, Ls):
+        assert np.abs(np.triu(L, 1)).max() == 0
+        assert np.abs(L @ L.T - M).max() <= 1e-13 * np.abs(M).max()
+        Lr = np.linalg.cholesky(M)
+        assert np.abs(L - Lr).max() <= 1e-9 * np.abs(Lr).max()
+
+
+def test_mfma_cholesky_barrier_weighted_matrix():
+    """the shape the IPM produces: H with curvature 1e-3 plus G' W G with weights spread over 14 decades"""
+    rng = np.random.default_rng(7)
+    n, m = 120, 752
+    G = rng.standard_normal((m, n)) * (rng.random((m, n)) < 0.05)
+    w = 10.0 ** rng.uniform(-4, 10, m)
+    M = 1e-3 * np.eye(n) + G.T @ (w[:, None] * G)
+    (L,), nreg = device_cholesky([M])
+    assert nreg[0] == 0
+    assert np.abs(L @ L.T - M).max() <= 1e-13 * np.abs(M).max()
+
+
+def test_mfma_cholesky_reports_indefinite_input():
+    n = 40
+    M = np.eye(n); M[17, 17] = -1.0
+    (L,), nreg = device_cholesky([M])
+    assert nreg[0] == 1
