@@ -189,10 +189,12 @@ __global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_cholesky(int n, const
     __syncthreads();
     DnTiles T;
     int nreg = 0;
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
     dn_load_packed(T, M, n);
     dn_cholesky(T, M, n, panel, &nreg);
+    const long long t1 = (long long)__builtin_amdgcn_s_memtime();
     for (int e = threadIdx.x; e < np; e += DN_THREADS) Lout[(size_t)blockIdx.x * np + e] = M[e];
-    if (threadIdx.x == 0) nreg_out[blockIdx.x] = nreg;
+    if (threadIdx.x == 0) nreg_out[blockIdx.x] = nreg | ((int)min((long long)0x7fffff, (t1 - t0) >> 4) << 8);   // bits 8..: ticks / 16 (diagnostic)
 }
 int srbm_debug_cholesky(int n, int count, const double* M_packed, double* L_packed, int* nreg) {
     if (n <= 0 || n > SRBM_NUMAX || count <= 0 || !M_packed || !L_packed || !nreg) return fail("bad arguments");
@@ -200,7 +202,7 @@ int srbm_debug_cholesky(int n, int count, const double* M_packed, double* L_pack
     double *dM = nullptr, *dL = nullptr; int* dr = nullptr;
     HIPCHK(hipMalloc(&dM, bytes)); HIPCHK(hipMalloc(&dL, bytes)); HIPCHK(hipMalloc(&dr, sizeof(int) * count));
     HIPCHK(hipMemcpy(dM, M_packed, bytes, hipMemcpyHostToDevice));
-    const size_t lds = ((size_t)SRBM_NUMAX * (SRBM_NUMAX + 1) / 2 + 2 * DN_PW * DN_TILE * DN_MAXT) * sizeof(double);
+    const size_t lds = ((size_t)SRBM_NUMAX * (SRBM_NUMAX + 1) / 2 + DN_PANEL_DOUBLES) * sizeof(double);
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k_debug_cholesky), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(srbm_k_debug_cholesky, dim3(count), dim3(DN_THREADS), lds, 0, n, dM, dL, dr);
     HIPCHK(hipGetLastError());

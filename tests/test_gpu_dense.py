@@ -32,7 +32,8 @@ def device_cholesky(mats):
     rc = lib.srbm_debug_cholesky(n, len(mats), inp.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double)),
                                  nreg.ctypes.data_as(C.POINTER(C.c_int)))
     assert rc == 0, lib.srbm_last_error().decode()
-    return [unpack(o, n) for o in out], nreg
+    device_cholesky.ticks = (nreg >> 8) * 16      # diagnostic: s_memtime ticks of load + factorisation
+    return [unpack(o, n) for o in out], nreg & 0xff
 
 
 @pytest.mark.parametrize('n', [1, 3, 4, 15, 16, 17, 63, 64, 118, 120, 157, 160])
