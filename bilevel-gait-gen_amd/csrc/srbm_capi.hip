@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "srbm_k4_update.hiph"
+#include "srbm_gait.hiph"
 #include "../../include/srbm_rti.h"
 
 static thread_local std::string g_err;
@@ -22,6 +23,7 @@ struct srbm_batch {
     SrbmWork* works = nullptr;
     double *d_state = nullptr, *d_time = nullptr, *d_ee = nullptr;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;
     size_t k3_lds = 0;
     bool params_dirty = true;
     // optional HIP-event timing of the dominant kernel (srbm_k3_ipm) on the launch stream
@@ -115,27 +117,7 @@ __global__ void srbm_k_set_contact_times(const SrbmParams* __restrict__ Pp, Srbm
     if (w >= Pp->batch * SRBM_NEE) return;
     const int b = w / SRBM_NEE, ee = w % SRBM_NEE;
     SrbmInst& I = insts[b];
-    const double* ct = times + ((size_t)b * SRBM_NEE + ee) * ld;
-    int ncontact = 0;
-    for (int i = 0; i < I.nk[ee]; i++) ncontact += (I.kind[ee][i] <= SRBM_K_TD);
-    int cidx = 0;
-    for (int i = 0; i < I.nk[ee]; i++) {
-        const int kd = I.kind[ee][i];
-        if (kd <= SRBM_K_TD) {
-            double t = ct[cidx];
-            if (t < 0 && fabs(t) < 1e-3) t = 0;
-            I.knot_t[ee][i] = t; cidx++;
-        } else if (kd == SRBM_K_MID) {
-            const double d = ct[cidx] - ct[cidx - 1];
-            const double h = d / 2;
-            I.knot_t[ee][i] = I.knot_t[ee][i - 1] + h;
-        } else {
-            double contact_time = 0.2 + ct[cidx - 1];
-            if (cidx < ncontact) contact_time = ct[cidx] - ct[cidx - 1];
-            const double h = contact_time / 3;
-            I.knot_t[ee][i] = I.knot_t[ee][i - 1] + h;
-        }
-    }
+    srbm_apply_contact_times(I, ee, times + ((size_t)b * SRBM_NEE + ee) * ld, srbm_num_contacts(I, ee));
 }
 
 // ---------------- host helpers ----------------
@@ -269,7 +251,7 @@ int srbm_batch_destroy(srbm_batch* h) {
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->dp); (void)hipFree(h->insts); (void)hipFree(h->works);
     (void)hipFree(h->d_state); (void)hipFree(h->d_time); (void)hipFree(h->d_ee);
-    (void)hipStreamDestroy(h->stream);
+    if (h->owns_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
 }
@@ -381,6 +363,121 @@ int srbm_update_contact_times(srbm_batch* h, const double* times, int max_contac
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipFree(d));
     return 0;
+}
+
+// ---------------- bilevel (gait) step: mpc::GaitOptimizer for the batch ----------------
+struct srbm_gait {
+    srbm_batch* h = nullptr;        // the instances being optimised
+    srbm_batch* ls = nullptr;       // LS_SIZE candidates per instance, same stream
+    double *xk = nullptr, *step = nullptr, *costs = nullptr, *dHdth = nullptr;   // [B][SRBM_GAIT_NV], costs [B][LS_SIZE]
+    int *counts = nullptr, *imin = nullptr;                                       // [B][4], [B]
+};
+
+static int make_candidate_batch(const srbm_batch* h, srbm_batch** out) {
+    auto* c = new srbm_batch;
+    c->batch = h->batch * SRBM_LS_SIZE; c->device = h->device;
+    c->hp = h->hp; c->hp.batch = c->batch;
+    c->stream = h->stream; c->owns_stream = false;
+    c->k3_lds = h->k3_lds;
+    const size_t B = c->batch;
+    HIPCHK(hipMalloc(&c->dp, sizeof(SrbmParams)));
+    HIPCHK(hipMalloc(&c->insts, sizeof(SrbmInst) * B));
+    HIPCHK(hipMalloc(&c->works, sizeof(SrbmWork) * B));
+    HIPCHK(hipMalloc(&c->d_state, sizeof(double) * 13 * B));
+    HIPCHK(hipMalloc(&c->d_time, sizeof(double) * B));
+    HIPCHK(hipMalloc(&c->d_ee, sizeof(double) * 12 * B));
+    HIPCHK(hipMemsetAsync(c->works, 0, sizeof(SrbmWork) * B, c->stream));
+    *out = c;
+    return 0;
+}
+
+int srbm_gait_create(srbm_batch* h, srbm_gait** out) {
+    if (!h || !out) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    auto* g = new srbm_gait;
+    g->h = h;
+    if (make_candidate_batch(h, &g->ls)) { delete g; return -1; }
+    const size_t B = h->batch;
+    HIPCHK(hipMalloc(&g->xk, sizeof(double) * SRBM_GAIT_NV * B));
+    HIPCHK(hipMalloc(&g->step, sizeof(double) * SRBM_GAIT_NV * B));
+    HIPCHK(hipMalloc(&g->dHdth, sizeof(double) * SRBM_GAIT_NV * B));
+    HIPCHK(hipMalloc(&g->costs, sizeof(double) * SRBM_LS_SIZE * B));
+    HIPCHK(hipMalloc(&g->counts, sizeof(int) * SRBM_NEE * B));
+    HIPCHK(hipMalloc(&g->imin, sizeof(int) * B));
+    HIPCHK(hipMemsetAsync(g->xk, 0, sizeof(double) * SRBM_GAIT_NV * B, h->stream));
+    HIPCHK(hipMemsetAsync(g->step, 0, sizeof(double) * SRBM_GAIT_NV * B, h->stream));
+    HIPCHK(hipMemsetAsync(g->dHdth, 0, sizeof(double) * SRBM_GAIT_NV * B, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *out = g;
+    return 0;
+}
+int srbm_gait_destroy(srbm_gait* g) {
+    if (!g) return 0;
+    (void)hipSetDevice(g->h->device);
+    (void)hipStreamSynchronize(g->h->stream);
+    srbm_batch_destroy(g->ls);
+    (void)hipFree(g->xk); (void)hipFree(g->step); (void)hipFree(g->dHdth); (void)hipFree(g->costs);
+    (void)hipFree(g->counts); (void)hipFree(g->imin);
+    delete g;
+    return 0;
+}
+// GaitOptimizer::SetContactTimes(mpc.GetTrajectory().GetContactTimes()) (gait_optimizer.cpp:395-408)
+int srbm_gait_set_contact_times_from_trajectory(srbm_gait* g) {
+    if (!g) return fail("bad arguments");
+    srbm_batch* h = g->h;
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    hipLaunchKernelGGL(srbm_k_gait_read_contact_times, dim3((h->batch + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts, g->xk, g->counts);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int srbm_gait_get_contact_times(srbm_gait* g, double* xk, int* counts) {
+    if (!g || !xk || !counts) return fail("bad arguments");
+    HIPCHK(hipSetDevice(g->h->device));
+    HIPCHK(hipStreamSynchronize(g->h->stream));
+    HIPCHK(hipMemcpy(xk, g->xk, sizeof(double) * SRBM_GAIT_NV * (size_t)g->h->batch, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(counts, g->counts, sizeof(int) * SRBM_NEE * (size_t)g->h->batch, hipMemcpyDeviceToHost));
+    return 0;
+}
+int srbm_gait_set_step(srbm_gait* g, const double* step) {
+    if (!g || !step) return fail("bad arguments");
+    HIPCHK(hipSetDevice(g->h->device));
+    HIPCHK(hipMemcpyAsync(g->step, step, sizeof(double) * SRBM_GAIT_NV * (size_t)g->h->batch, hipMemcpyHostToDevice, g->h->stream));
+    HIPCHK(hipStreamSynchronize(g->h->stream));
+    return 0;
+}
+int srbm_gait_get_step(srbm_gait* g, double* step) {
+    if (!g || !step) return fail("bad arguments");
+    HIPCHK(hipSetDevice(g->h->device));
+    HIPCHK(hipStreamSynchronize(g->h->stream));
+    HIPCHK(hipMemcpy(step, g->step, sizeof(double) * SRBM_GAIT_NV * (size_t)g->h->batch, hipMemcpyDeviceToHost));
+    return 0;
+}
+// GaitOptimizer::LineSearch (gait_optimizer.cpp:671-753)
+int srbm_gait_line_search(srbm_gait* g, const double* state, const double* time, const double* ee, int* imin, double* costs) {
+    if (!g || !state || !time || !ee) return fail("bad arguments");
+    srbm_batch* h = g->h; srbm_batch* ls = g->ls;
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_inputs(h, state, time, ee)) return -1;
+    if (upload_params(h)) return -1;
+    const int B = h->batch;
+    ls->hp = h->hp; ls->hp.batch = ls->batch; ls->params_dirty = true;      // costs / tolerances may have changed since creation
+    if (upload_params(ls)) return -1;
+    hipLaunchKernelGGL(srbm_k_gait_spawn_candidates, dim3(B * SRBM_LS_SIZE), dim3(128), 0, h->stream, h->dp, h->insts, ls->insts,
+                       g->xk, g->step, h->d_state, h->d_time, h->d_ee, ls->d_state, ls->d_time, ls->d_ee);
+    HIPCHK(hipGetLastError());
+    if (launch_step(ls)) return -1;
+    hipLaunchKernelGGL(srbm_k_gait_select, dim3(B), dim3(128), 0, h->stream, h->dp, h->insts, ls->insts, g->imin, g->costs);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (imin) HIPCHK(hipMemcpy(imin, g->imin, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost));
+    if (costs) HIPCHK(hipMemcpy(costs, g->costs, sizeof(double) * SRBM_LS_SIZE * (size_t)B, hipMemcpyDeviceToHost));
+    return 0;
+}
+/* status / stats of the candidates of the last line search: status[batch][10], iters[batch][10] (diagnostic) */
+int srbm_gait_get_candidate_status(srbm_gait* g, int* status, int* err) {
+    if (!g || !status || !err) return fail("bad arguments");
+    return srbm_get_status(g->ls, status, err);
 }
 
 int srbm_enable_kernel_timing(srbm_batch* h, int max_launches) {

@@ -251,3 +251,57 @@ class BatchMPC:
         A = np.zeros((m, n)); b = np.zeros(m); P = np.zeros((n, n)); q = np.zeros(n)
         self._chk(self.L.srbm_export_qp(self.h, int(inst), _d(A), _d(b), _d(P), _d(q)))
         return A, b, P, q
+
+
+class BatchGaitOptimizer:
+    """mpc::GaitOptimizer (/root/reference/mpc/include/gait_optimizer.h) for every instance of a BatchMPC: same method
+    names in snake_case, contact-time vectors as [batch][32] rows (foot after foot, `counts` entries per foot)."""
+    NV = 32
+    LS_SIZE = 10
+
+    def __init__(self, mpc):
+        self.mpc = mpc
+        self.L = mpc.L
+        self.g = C.c_void_p()
+        mpc._chk(self.L.srbm_gait_create(mpc.h, C.byref(self.g)))
+
+    def __del__(self):
+        try:
+            if self.g:
+                self.L.srbm_gait_destroy(self.g)
+                self.g = None
+        except Exception:
+            pass
+
+    def set_contact_times_from_trajectory(self):
+        self.mpc._chk(self.L.srbm_gait_set_contact_times_from_trajectory(self.g))
+
+    def contact_times(self):
+        xk = np.zeros((self.mpc.batch, self.NV)); counts = np.zeros((self.mpc.batch, 4), np.int32)
+        self.mpc._chk(self.L.srbm_gait_get_contact_times(self.g, _d(xk), _i(counts)))
+        return xk, counts
+
+    def set_step(self, step):
+        a = np.zeros((self.mpc.batch, self.NV))
+        st = np.asarray(step, dtype=np.float64)
+        a[:, :st.shape[-1]] = st
+        self.mpc._chk(self.L.srbm_gait_set_step(self.g, _d(a)))
+
+    def step(self):
+        a = np.zeros((self.mpc.batch, self.NV))
+        self.mpc._chk(self.L.srbm_gait_get_step(self.g, _d(a)))
+        return a
+
+    def line_search(self, state, init_time, ee):
+        m = self.mpc
+        s = m._bcast(state, 13); e = m._bcast(ee, 12)
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(init_time, dtype=np.float64), (m.batch,)))
+        imin = np.zeros(m.batch, np.int32); costs = np.zeros((m.batch, self.LS_SIZE))
+        m._chk(self.L.srbm_gait_line_search(self.g, _d(s), _d(t), _d(e), _i(imin), _d(costs)))
+        return imin, costs
+
+    def candidate_status(self):
+        n = self.mpc.batch * self.LS_SIZE
+        st = np.zeros(n, np.int32); err = np.zeros(n, np.int32)
+        self.mpc._chk(self.L.srbm_gait_get_candidate_status(self.g, _i(st), _i(err)))
+        return st.reshape(-1, self.LS_SIZE), err.reshape(-1, self.LS_SIZE)

@@ -64,6 +64,29 @@ void* srbm_stream(srbm_batch* h);            /* hipStream_t the kernels are laun
  * number of contact knots of every foot */
 int srbm_update_contact_times(srbm_batch* h, const double* times, int max_contacts);
 
+/* ---- bilevel (gait) step: mpc::GaitOptimizer (mpc/include/gait_optimizer.h:20-170) for every instance of a batch ----
+ * Contact-time vectors are laid out as in the reference's QP vector (gait_optimizer.cpp:395-408): foot after foot,
+ * counts[batch][4] contact times per foot, row stride SRBM_GAIT_NV = 32 doubles per instance. */
+#define SRBM_GAIT_NV 32
+#define SRBM_GAIT_LS_SIZE 10      /* gait_optimizer.h:164 */
+typedef struct srbm_gait srbm_gait;
+/* GaitOptimizer::GaitOptimizer + UpdateSizes (gait_optimizer.cpp:15-63): allocates the 10 line-search candidates per instance */
+int srbm_gait_create(srbm_batch* h, srbm_gait** out);
+int srbm_gait_destroy(srbm_gait* g);
+/* GaitOptimizer::SetContactTimes(mpc.GetTrajectory().GetContactTimes()) (gait_optimizer.cpp:395-408, mpc_controller.cpp:528) */
+int srbm_gait_set_contact_times_from_trajectory(srbm_gait* g);
+int srbm_gait_get_contact_times(srbm_gait* g, double* xk, int* counts);
+/* step of the outer problem (result of OptimizeContactTimes, or supplied by the caller): step[batch][32] */
+int srbm_gait_set_step(srbm_gait* g, const double* step);
+int srbm_gait_get_step(srbm_gait* g, double* step);
+/* GaitOptimizer::LineSearch (gait_optimizer.cpp:671-753): 10 schedules x_k + (i/10) step per instance, each a full
+ * MPC::GetRealTimeUpdate(state, time, ee) on a copy of the instance (inputs as srbm_get_real_time_update); the cheapest
+ * candidate (cost / n, primal-infeasible ones excluded, index 0 if all are) is installed with
+ * MPC::SetWarmStartTrajectory.  imin[batch], costs[batch][10] may be NULL. */
+int srbm_gait_line_search(srbm_gait* g, const double* state, const double* init_time, const double* ee, int* imin, double* costs);
+/* solver status / error bits of the candidates of the last line search: status[batch*10], err[batch*10] */
+int srbm_gait_get_candidate_status(srbm_gait* g, int* status, int* err);
+
 /* ---- results (all copied to host) ---- */
 /* sizes[batch][8] = n, m, n_eq, n_ineq, n_force_vars, n_pos_vars, n_td_rows, n_force_samples */
 int srbm_get_sizes(srbm_batch* h, int* sizes);
