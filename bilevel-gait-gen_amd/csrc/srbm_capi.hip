@@ -371,6 +371,7 @@ struct srbm_gait {
     srbm_batch* ls = nullptr;       // LS_SIZE candidates per instance, same stream
     double *xk = nullptr, *step = nullptr, *costs = nullptr, *dHdth = nullptr;   // [B][SRBM_GAIT_NV], costs [B][LS_SIZE]
     int *counts = nullptr, *imin = nullptr;                                       // [B][4], [B]
+    SrbmGaitWork* gw = nullptr;                                                   // sensitivity workspace, one per instance
 };
 
 static int make_candidate_batch(const srbm_batch* h, srbm_batch** out) {
@@ -404,6 +405,9 @@ int srbm_gait_create(srbm_batch* h, srbm_gait** out) {
     HIPCHK(hipMalloc(&g->costs, sizeof(double) * SRBM_LS_SIZE * B));
     HIPCHK(hipMalloc(&g->counts, sizeof(int) * SRBM_NEE * B));
     HIPCHK(hipMalloc(&g->imin, sizeof(int) * B));
+    HIPCHK(hipMalloc(&g->gw, sizeof(SrbmGaitWork) * B));
+    HIPCHK(hipMemsetAsync(g->gw, 0, sizeof(SrbmGaitWork) * B, h->stream));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_normal_matrix), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
     HIPCHK(hipMemsetAsync(g->xk, 0, sizeof(double) * SRBM_GAIT_NV * B, h->stream));
     HIPCHK(hipMemsetAsync(g->step, 0, sizeof(double) * SRBM_GAIT_NV * B, h->stream));
     HIPCHK(hipMemsetAsync(g->dHdth, 0, sizeof(double) * SRBM_GAIT_NV * B, h->stream));
@@ -417,7 +421,7 @@ int srbm_gait_destroy(srbm_gait* g) {
     (void)hipStreamSynchronize(g->h->stream);
     srbm_batch_destroy(g->ls);
     (void)hipFree(g->xk); (void)hipFree(g->step); (void)hipFree(g->dHdth); (void)hipFree(g->costs);
-    (void)hipFree(g->counts); (void)hipFree(g->imin);
+    (void)hipFree(g->counts); (void)hipFree(g->imin); (void)hipFree(g->gw);
     delete g;
     return 0;
 }
@@ -451,6 +455,32 @@ int srbm_gait_get_step(srbm_gait* g, double* step) {
     HIPCHK(hipSetDevice(g->h->device));
     HIPCHK(hipStreamSynchronize(g->h->stream));
     HIPCHK(hipMemcpy(step, g->step, sizeof(double) * SRBM_GAIT_NV * (size_t)g->h->batch, hipMemcpyDeviceToHost));
+    return 0;
+}
+// MPC::ComputeDerivativeTerms (mpc.cpp:1047-1069): KKT sensitivity d = [dz; dlam; dnu] of the last QP solution
+int srbm_gait_compute_sensitivity(srbm_gait* g) {
+    if (!g) return fail("bad arguments");
+    srbm_batch* h = g->h;
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    hipLaunchKernelGGL(srbm_k3_normal_matrix, dim3(h->batch), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works);
+    hipLaunchKernelGGL(srbm_k_gait_sensitivity, dim3(h->batch), dim3(KG_THREADS), 0, h->stream, h->dp, h->insts, h->works, g->gw);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int srbm_gait_get_sensitivity(srbm_gait* g, double* d, int ld) {
+    if (!g || !d || ld <= 0) return fail("bad arguments");
+    srbm_batch* h = g->h;
+    HIPCHK(hipSetDevice(h->device));
+    double* dev = nullptr;
+    const size_t bytes = sizeof(double) * (size_t)h->batch * ld;
+    HIPCHK(hipMalloc(&dev, bytes));
+    HIPCHK(hipMemsetAsync(dev, 0, bytes, h->stream));
+    hipLaunchKernelGGL(srbm_k_gait_pack_d, dim3(h->batch), dim3(128), 0, h->stream, h->dp, h->insts, h->works, g->gw, dev, ld);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(d, dev, bytes, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(dev));
     return 0;
 }
 // GaitOptimizer::LineSearch (gait_optimizer.cpp:671-753)

@@ -106,6 +106,7 @@ typedef struct SrbmWork {
     double x[SRBM_NXMAX];                         /* prev_qp_sol after the line search */
     double z[SRBM_MMAX];                          /* dual vector in the reference's row order */
     double s[SRBM_MMAX];
+    double Ms[SRBM_HPACK];                        /* gait step: H + G' diag(lambda/s) G of the last solution (srbm_k3_normal_matrix) */
     double w0[SRBM_MIMAX];                        /* IPM: unit weight of the row/cost-scaled problem, e_r^2 / c (kernel 3 scratch) */
     double prof[16];                              /* diagnostic builds only (-DSRBM_PROFILE): cycles per IPM phase */
     double dbg[4 * 64];

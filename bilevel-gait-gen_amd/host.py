@@ -281,6 +281,16 @@ class BatchGaitOptimizer:
         self.mpc._chk(self.L.srbm_gait_get_contact_times(self.g, _d(xk), _i(counts)))
         return xk, counts
 
+    def compute_sensitivity(self):
+        self.mpc._chk(self.L.srbm_gait_compute_sensitivity(self.g))
+
+    def sensitivity(self):
+        m = self.mpc
+        ld = (m.N + 1) * 12 + 160 + 6 * 120 + 16 * (m.N - 3) + (m.N + 1) * 12 + 16
+        d = np.zeros((m.batch, ld))
+        m._chk(self.L.srbm_gait_get_sensitivity(self.g, _d(d), ld))
+        return d
+
     def set_step(self, step):
         a = np.zeros((self.mpc.batch, self.NV))
         st = np.asarray(step, dtype=np.float64)

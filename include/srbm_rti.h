@@ -76,6 +76,10 @@ int srbm_gait_destroy(srbm_gait* g);
 /* GaitOptimizer::SetContactTimes(mpc.GetTrajectory().GetContactTimes()) (gait_optimizer.cpp:395-408, mpc_controller.cpp:528) */
 int srbm_gait_set_contact_times_from_trajectory(srbm_gait* g);
 int srbm_gait_get_contact_times(srbm_gait* g, double* xk, int* counts);
+/* MPC::ComputeDerivativeTerms -> ClarabelInterface::Computedx (mpc/mpc.cpp:1047-1069, mpc/qp/clarabel_interface.cpp:262-612):
+ * KKT sensitivity of the last QP solution, d[batch][ld] = [dz (n); dlam (n_ineq, constraint order); dnu (n_eq)] */
+int srbm_gait_compute_sensitivity(srbm_gait* g);
+int srbm_gait_get_sensitivity(srbm_gait* g, double* d, int ld);
 /* step of the outer problem (result of OptimizeContactTimes, or supplied by the caller): step[batch][32] */
 int srbm_gait_set_step(srbm_gait* g, const double* step);
 int srbm_gait_get_step(srbm_gait* g, double* step);

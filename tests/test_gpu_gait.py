@@ -75,3 +75,65 @@ def test_candidate_line_search_matches_oracle(cfgname, nsteps):
     n = o.sizes()['n']
     assert (g.sizes()[0, 0], g.sizes()[0, 1]) == (n, o.sizes()['m'])
     assert relerr(g.qp_solution()[0, :n], o.x()) < REL_TOL
+
+
+def as_coded_sensitivity(A, P, q, xs, z, s, nx, mi):
+    """dense restatement of clarabel_interface.cpp:262-612 in the full space (numpy), rows of all-zero coefficients left out"""
+    n, m = P.shape[0], A.shape[0]
+    ineq = np.arange(nx, nx + mi); eq = np.concatenate([np.arange(nx), np.arange(nx + mi, m)])
+    G, Ae = A[ineq], A[eq]
+    lam, sl = z[ineq], s[ineq]
+    K = np.zeros((n + m, n + m))
+    K[:n, :n] = P; K[:n, n:n + mi] = G.T * lam[None, :]; K[:n, n + mi:] = Ae.T
+    K[n:n + mi, :n] = G; K[n:n + mi, n:n + mi] = np.diag(sl)
+    K[n + mi:, :n] = Ae
+    rhs = np.zeros(n + m); rhs[:n] = -(P @ xs + q)
+    live = np.abs(G).max(axis=1) > 0
+    keep = np.concatenate([np.ones(n, bool), live, np.ones(len(eq), bool)])
+    sol = np.zeros(n + m)
+    sol[keep] = np.linalg.solve(K[np.ix_(keep, keep)], rhs[keep])
+    return sol, live, lam
+
+
+@pytest.mark.parametrize('cfgname,nsteps', [('a1_configuration', 3), ('a1_configuration', 8), ('a1_gait_opt_config', 2)])
+def test_kkt_sensitivity(cfgname, nsteps):
+    """a12: d = [dz; dlam; dnu] of clarabel_interface.cpp:262-612 (as coded, +diag(s)).  The device solves it in the
+    condensed coordinates; (1) that must equal the full-space system solved densely in numpy on the SAME QP, solution
+    and multipliers (tight); (2) against the oracle only the well-posed parts are compared: with exact complementarity
+    the system's solution is (0, 1, nu), what remains is -s_i on degenerate rows (lambda_i and s_i both ~ sqrt(mu)),
+    whose size is a property of the interior-point path of each solver, not of the QP."""
+    cfg, g, o, state, ee, t = run_pair(cfgname, nsteps)
+    assert o.stats()['status'] == 0 and g.status()[0][0] == 0
+    assert o.gait_gradient() is not None
+    do = o.gait_d()
+    gait = host.BatchGaitOptimizer(g)
+    gait.compute_sensitivity()
+    d = gait.sensitivity()
+    sz = o.sizes()
+    n, mi, me = sz['n'], sz['n_ineq'], sz['n_eq']
+    nx = (cfg['num_nodes'] + 1) * 12
+    assert np.array_equal(d[0], d[1])
+    dz, dl, dn = d[0, :n], d[0, n:n + mi], d[0, n + mi:n + mi + me]
+    # (1) same linear system, same data, dense full-space solve
+    A, bvec, P, q = g.export_qp(0)
+    z, s = g.dual_solution()
+    sol, live, lam = as_coded_sensitivity(A, P, q, g.qp_solution()[0, :n], z[0], s[0], nx, mi)
+    assert np.abs(dz - sol[:n]).max() <= 1e-6 * max(1.0, np.abs(sol[:n]).max())
+    assert np.abs(dn - sol[n + mi:]).max() <= 1e-6 * max(1.0, np.abs(sol[n + mi:]).max())
+    # dlam_i = -(G dz)_i / s_i amplifies rounding by 1/s_i on active rows, in any implementation: check it through the
+    # residuals of the three block rows instead of entry by entry
+    m = A.shape[0]
+    ineq = np.arange(nx, nx + mi); eq = np.concatenate([np.arange(nx), np.arange(nx + mi, m)])
+    G, Ae = A[ineq], A[eq]
+    xg = g.qp_solution()[0, :n]
+    mu_g = lam * dl
+    dldx = P @ xg + q
+    r1 = P @ dz + G.T @ mu_g + Ae.T @ dn + dldx
+    assert np.abs(r1).max() <= 1e-5 * max(1.0, np.abs(dldx).max())
+    assert np.abs(G @ dz + s[0, ineq] * dl)[live].max() <= 1e-9
+    assert np.abs(Ae @ dz).max() <= 1e-9
+    # (2) oracle: dq = dz + x*, dh = -lam o dlam, db = -dnu (the QP partials the gradient is built from)
+    xo = o.x(); lam_o = o.z()[nx:nx + mi]
+    assert relerr(dz + xg, do[:n] + xo) < REL_TOL
+    assert np.abs(mu_g - lam_o * do[n:n + mi])[live].max() <= 2e-3 * max(1.0, np.abs(lam_o).max())
+    assert np.abs(dn - do[n + mi:]).max() <= 2e-3 * max(1.0, np.abs(do[n + mi:]).max())
