@@ -370,7 +370,7 @@ struct srbm_gait {
     srbm_batch* h = nullptr;        // the instances being optimised
     srbm_batch* ls = nullptr;       // LS_SIZE candidates per instance, same stream
     double *xk = nullptr, *step = nullptr, *costs = nullptr, *dHdth = nullptr;   // [B][SRBM_GAIT_NV], costs [B][LS_SIZE]
-    int *counts = nullptr, *imin = nullptr;                                       // [B][4], [B]
+    int *counts = nullptr, *imin = nullptr, *valid = nullptr;                     // [B][4], [B], [B]
     SrbmGaitWork* gw = nullptr;                                                   // sensitivity workspace, one per instance
 };
 
@@ -405,6 +405,8 @@ int srbm_gait_create(srbm_batch* h, srbm_gait** out) {
     HIPCHK(hipMalloc(&g->costs, sizeof(double) * SRBM_LS_SIZE * B));
     HIPCHK(hipMalloc(&g->counts, sizeof(int) * SRBM_NEE * B));
     HIPCHK(hipMalloc(&g->imin, sizeof(int) * B));
+    HIPCHK(hipMalloc(&g->valid, sizeof(int) * B));
+    HIPCHK(hipMemsetAsync(g->valid, 0, sizeof(int) * B, h->stream));
     HIPCHK(hipMalloc(&g->gw, sizeof(SrbmGaitWork) * B));
     HIPCHK(hipMemsetAsync(g->gw, 0, sizeof(SrbmGaitWork) * B, h->stream));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_normal_matrix), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
@@ -421,7 +423,7 @@ int srbm_gait_destroy(srbm_gait* g) {
     (void)hipStreamSynchronize(g->h->stream);
     srbm_batch_destroy(g->ls);
     (void)hipFree(g->xk); (void)hipFree(g->step); (void)hipFree(g->dHdth); (void)hipFree(g->costs);
-    (void)hipFree(g->counts); (void)hipFree(g->imin); (void)hipFree(g->gw);
+    (void)hipFree(g->counts); (void)hipFree(g->imin); (void)hipFree(g->gw); (void)hipFree(g->valid);
     delete g;
     return 0;
 }
@@ -466,6 +468,25 @@ int srbm_gait_compute_sensitivity(srbm_gait* g) {
     hipLaunchKernelGGL(srbm_k3_normal_matrix, dim3(h->batch), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works);
     hipLaunchKernelGGL(srbm_k_gait_sensitivity, dim3(h->batch), dim3(KG_THREADS), 0, h->stream, h->dp, h->insts, h->works, g->gw);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+// mpc_controller.cpp:518-561: SetContactTimes, ComputeDerivativeTerms / GetQPPartials, the 20 parameter partials and
+// GaitOptimizer::ComputeCostFcnDerivWrtContactTimes, for every instance.  dHdth stays on the device for the LP.
+int srbm_gait_compute_gradient(srbm_gait* g) {
+    if (!g) return fail("bad arguments");
+    srbm_batch* h = g->h;
+    if (srbm_gait_set_contact_times_from_trajectory(g)) return -1;
+    if (srbm_gait_compute_sensitivity(g)) return -1;
+    hipLaunchKernelGGL(srbm_k_gait_gradient, dim3(h->batch), dim3(KH_THREADS), 0, h->stream, h->dp, h->insts, h->works, g->gw, g->dHdth, g->valid);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int srbm_gait_get_gradient(srbm_gait* g, double* dHdth, int* valid) {
+    if (!g || !dHdth) return fail("bad arguments");
+    HIPCHK(hipSetDevice(g->h->device));
+    HIPCHK(hipStreamSynchronize(g->h->stream));
+    HIPCHK(hipMemcpy(dHdth, g->dHdth, sizeof(double) * SRBM_GAIT_NV * (size_t)g->h->batch, hipMemcpyDeviceToHost));
+    if (valid) HIPCHK(hipMemcpy(valid, g->valid, sizeof(int) * (size_t)g->h->batch, hipMemcpyDeviceToHost));
     return 0;
 }
 int srbm_gait_get_sensitivity(srbm_gait* g, double* d, int ld) {

@@ -291,6 +291,15 @@ class BatchGaitOptimizer:
         m._chk(self.L.srbm_gait_get_sensitivity(self.g, _d(d), ld))
         return d
 
+    def compute_gradient(self):
+        self.mpc._chk(self.L.srbm_gait_compute_gradient(self.g))
+
+    def gradient(self):
+        m = self.mpc
+        g = np.zeros((m.batch, self.NV)); valid = np.zeros(m.batch, np.int32)
+        m._chk(self.L.srbm_gait_get_gradient(self.g, _d(g), _i(valid)))
+        return g, valid
+
     def set_step(self, step):
         a = np.zeros((self.mpc.batch, self.NV))
         st = np.asarray(step, dtype=np.float64)

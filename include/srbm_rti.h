@@ -80,6 +80,12 @@ int srbm_gait_get_contact_times(srbm_gait* g, double* xk, int* counts);
  * KKT sensitivity of the last QP solution, d[batch][ld] = [dz (n); dlam (n_ineq, constraint order); dnu (n_eq)] */
 int srbm_gait_compute_sensitivity(srbm_gait* g);
 int srbm_gait_get_sensitivity(srbm_gait* g, double* d, int ld);
+/* The gradient of the optimal cost w.r.t. the contact times (mpc_controller.cpp:518-561): SetContactTimes,
+ * ComputeDerivativeTerms, MPCSingleRigidBody::ComputeParamPartialsClarabel for every contact time (mpc_single_rigid_body.cpp:
+ * 642-792) and GaitOptimizer::ComputeCostFcnDerivWrtContactTimes (gait_optimizer.cpp:92-179).  dHdth[batch][32];
+ * valid[batch] = 0 where the reference refuses (last QP not Solved, mpc.cpp:1048) -- may be NULL */
+int srbm_gait_compute_gradient(srbm_gait* g);
+int srbm_gait_get_gradient(srbm_gait* g, double* dHdth, int* valid);
 /* step of the outer problem (result of OptimizeContactTimes, or supplied by the caller): step[batch][32] */
 int srbm_gait_set_step(srbm_gait* g, const double* step);
 int srbm_gait_get_step(srbm_gait* g, double* step);

@@ -137,3 +137,23 @@ def test_kkt_sensitivity(cfgname, nsteps):
     assert relerr(dz + xg, do[:n] + xo) < REL_TOL
     assert np.abs(mu_g - lam_o * do[n:n + mi])[live].max() <= 2e-3 * max(1.0, np.abs(lam_o).max())
     assert np.abs(dn - do[n + mi:]).max() <= 2e-3 * max(1.0, np.abs(do[n + mi:]).max())
+
+
+@pytest.mark.parametrize('cfgname,nsteps', [('a1_configuration', 3), ('a1_configuration', 8), ('a1_configuration', 13),
+                                            ('a1_gait_opt_config', 2), ('a1_config_distr_rejection', 4)])
+def test_cost_gradient_wrt_contact_times_matches_oracle(cfgname, nsteps):
+    """a13 + a14: dH/dtheta for every contact time.  Tolerance 1e-3 of the largest entry: the terms carried by dz and
+    dlam are solver-path dependent on degenerate rows (see test_kkt_sensitivity); the envelope part dominates."""
+    cfg, g, o, state, ee, t = run_pair(cfgname, nsteps)
+    assert o.stats()['status'] == 0 and g.status()[0][0] == 0
+    go = o.gait_gradient()
+    assert go is not None
+    gait = host.BatchGaitOptimizer(g)
+    gait.compute_gradient()
+    gg, valid = gait.gradient()
+    xk, counts = gait.contact_times()
+    nv = len(go)
+    assert valid[0] == 1 and counts[0].sum() == nv
+    assert np.array_equal(gg[0], gg[1])
+    assert np.all(gg[0, nv:] == 0)
+    assert np.abs(gg[0, :nv] - go).max() <= 1e-3 * max(1.0, np.abs(go).max()), (gg[0, :nv], go)
