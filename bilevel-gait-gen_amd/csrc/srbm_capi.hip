@@ -370,7 +370,9 @@ struct srbm_gait {
     srbm_batch* h = nullptr;        // the instances being optimised
     srbm_batch* ls = nullptr;       // LS_SIZE candidates per instance, same stream
     double *xk = nullptr, *step = nullptr, *costs = nullptr, *dHdth = nullptr;   // [B][SRBM_GAIT_NV], costs [B][LS_SIZE]
-    int *counts = nullptr, *imin = nullptr, *valid = nullptr;                     // [B][4], [B], [B]
+    int *counts = nullptr, *imin = nullptr, *valid = nullptr, *lp_status = nullptr;   // [B][4], [B], [B], [B]
+    double* pred_red = nullptr;                                                   // [B]
+    int* ready = nullptr;                                                         // [B] deriv_ready of the controller
     SrbmGaitWork* gw = nullptr;                                                   // sensitivity workspace, one per instance
 };
 
@@ -406,6 +408,12 @@ int srbm_gait_create(srbm_batch* h, srbm_gait** out) {
     HIPCHK(hipMalloc(&g->counts, sizeof(int) * SRBM_NEE * B));
     HIPCHK(hipMalloc(&g->imin, sizeof(int) * B));
     HIPCHK(hipMalloc(&g->valid, sizeof(int) * B));
+    HIPCHK(hipMalloc(&g->lp_status, sizeof(int) * B));
+    HIPCHK(hipMalloc(&g->pred_red, sizeof(double) * B));
+    HIPCHK(hipMalloc(&g->ready, sizeof(int) * B));
+    HIPCHK(hipMemsetAsync(g->ready, 0, sizeof(int) * B, h->stream));
+    HIPCHK(hipMemsetAsync(g->lp_status, 0, sizeof(int) * B, h->stream));
+    HIPCHK(hipMemsetAsync(g->pred_red, 0, sizeof(double) * B, h->stream));
     HIPCHK(hipMemsetAsync(g->valid, 0, sizeof(int) * B, h->stream));
     HIPCHK(hipMalloc(&g->gw, sizeof(SrbmGaitWork) * B));
     HIPCHK(hipMemsetAsync(g->gw, 0, sizeof(SrbmGaitWork) * B, h->stream));
@@ -423,7 +431,7 @@ int srbm_gait_destroy(srbm_gait* g) {
     (void)hipStreamSynchronize(g->h->stream);
     srbm_batch_destroy(g->ls);
     (void)hipFree(g->xk); (void)hipFree(g->step); (void)hipFree(g->dHdth); (void)hipFree(g->costs);
-    (void)hipFree(g->counts); (void)hipFree(g->imin); (void)hipFree(g->gw); (void)hipFree(g->valid);
+    (void)hipFree(g->counts); (void)hipFree(g->imin); (void)hipFree(g->gw); (void)hipFree(g->valid); (void)hipFree(g->lp_status); (void)hipFree(g->pred_red); (void)hipFree(g->ready);
     delete g;
     return 0;
 }
@@ -504,25 +512,94 @@ int srbm_gait_get_sensitivity(srbm_gait* g, double* d, int ld) {
     HIPCHK(hipFree(dev));
     return 0;
 }
+// GaitOptimizer::OptimizeContactTimes (gait_optimizer.cpp:185-364): the LP over the contact-time step; time[batch]
+int srbm_gait_optimize_contact_times(srbm_gait* g, const double* time) {
+    if (!g || !time) return fail("bad arguments");
+    srbm_batch* h = g->h;
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    HIPCHK(hipMemcpyAsync(h->d_time, time, sizeof(double) * (size_t)h->batch, hipMemcpyHostToDevice, h->stream));
+    const int threads = h->batch * SRBM_NEE;
+    hipLaunchKernelGGL(srbm_k_gait_lp, dim3((threads + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts, g->xk, g->counts, g->dHdth, h->d_time,
+                       g->step, g->pred_red, g->lp_status);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int srbm_gait_get_lp_result(srbm_gait* g, int* lp_status, double* pred_red) {
+    if (!g) return fail("bad arguments");
+    HIPCHK(hipSetDevice(g->h->device));
+    HIPCHK(hipStreamSynchronize(g->h->stream));
+    if (lp_status) HIPCHK(hipMemcpy(lp_status, g->lp_status, sizeof(int) * (size_t)g->h->batch, hipMemcpyDeviceToHost));
+    if (pred_red) HIPCHK(hipMemcpy(pred_red, g->pred_red, sizeof(double) * (size_t)g->h->batch, hipMemcpyDeviceToHost));
+    return 0;
+}
+// candidates -> 10*B solves -> argmin + install; inputs already in h->d_state / d_time / d_ee
+static int line_search_core(srbm_gait* g, bool use_ready_mask) {
+    srbm_batch* h = g->h; srbm_batch* ls = g->ls;
+    const int B = h->batch;
+    if (upload_params(h)) return -1;
+    ls->hp = h->hp; ls->hp.batch = ls->batch; ls->params_dirty = true;      // costs / tolerances may have changed since creation
+    if (upload_params(ls)) return -1;
+    const int* ready = use_ready_mask ? g->ready : nullptr;
+    hipLaunchKernelGGL(srbm_k_gait_spawn_candidates, dim3(B * SRBM_LS_SIZE), dim3(128), 0, h->stream, h->dp, h->insts, ls->insts,
+                       g->xk, g->step, h->d_state, h->d_time, h->d_ee, ls->d_state, ls->d_time, ls->d_ee, ready);
+    HIPCHK(hipGetLastError());
+    if (launch_step(ls)) return -1;
+    hipLaunchKernelGGL(srbm_k_gait_select, dim3(B), dim3(128), 0, h->stream, h->dp, h->insts, ls->insts, ready, g->imin, g->costs);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 // GaitOptimizer::LineSearch (gait_optimizer.cpp:671-753)
 int srbm_gait_line_search(srbm_gait* g, const double* state, const double* time, const double* ee, int* imin, double* costs) {
     if (!g || !state || !time || !ee) return fail("bad arguments");
-    srbm_batch* h = g->h; srbm_batch* ls = g->ls;
+    srbm_batch* h = g->h;
     HIPCHK(hipSetDevice(h->device));
     if (upload_inputs(h, state, time, ee)) return -1;
-    if (upload_params(h)) return -1;
+    if (line_search_core(g, false)) return -1;
     const int B = h->batch;
-    ls->hp = h->hp; ls->hp.batch = ls->batch; ls->params_dirty = true;      // costs / tolerances may have changed since creation
-    if (upload_params(ls)) return -1;
-    hipLaunchKernelGGL(srbm_k_gait_spawn_candidates, dim3(B * SRBM_LS_SIZE), dim3(128), 0, h->stream, h->dp, h->insts, ls->insts,
-                       g->xk, g->step, h->d_state, h->d_time, h->d_ee, ls->d_state, ls->d_time, ls->d_ee);
-    HIPCHK(hipGetLastError());
-    if (launch_step(ls)) return -1;
-    hipLaunchKernelGGL(srbm_k_gait_select, dim3(B), dim3(128), 0, h->stream, h->dp, h->insts, ls->insts, g->imin, g->costs);
-    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     if (imin) HIPCHK(hipMemcpy(imin, g->imin, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost));
     if (costs) HIPCHK(hipMemcpy(costs, g->costs, sizeof(double) * SRBM_LS_SIZE * (size_t)B, hipMemcpyDeviceToHost));
+    return 0;
+}
+// MPCController::GaitOpt (mpc_controller.cpp:518-566): gradient + LP at `time`; sets deriv_ready per instance
+static int gait_opt_core(srbm_gait* g) {        // time already in h->d_time
+    srbm_batch* h = g->h;
+    if (srbm_gait_compute_gradient(g)) return -1;
+    const int threads = h->batch * SRBM_NEE;
+    hipLaunchKernelGGL(srbm_k_gait_lp, dim3((threads + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts, g->xk, g->counts, g->dHdth, h->d_time,
+                       g->step, g->pred_red, g->lp_status);
+    hipLaunchKernelGGL(srbm_k_gait_ready, dim3((h->batch + 63) / 64), dim3(64), 0, h->stream, h->dp, g->valid, g->lp_status, g->ready, -1);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// The MPC loop of the controller with the bilevel step folded in (mpc_controller.cpp:320-346), device-resident and
+// open-loop as srbm_rti_advance (state := node 1 of the previous trajectory, time = run_num * dt):
+//   run_num % freq == 0 and a gradient is ready  -> LineSearch only (its 10 candidates are the RTI solves of this step)
+//   (run_num + 1) % freq == 0                     -> GetRealTimeUpdate, then GaitOpt (gradient + LP for the next step)
+//   otherwise                                     -> GetRealTimeUpdate
+int srbm_gait_rti_advance(srbm_gait* g, int first_run_num, int steps, int gait_opt_freq) {
+    if (!g || steps < 0 || gait_opt_freq <= 0) return fail("bad arguments");
+    srbm_batch* h = g->h;
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    for (int i = 0; i < steps; i++) {
+        const int run_num = first_run_num + i;
+        const double time = run_num * h->hp.dt;
+        hipLaunchKernelGGL(srbm_k_next_inputs, dim3(h->batch), dim3(64), 0, h->stream, h->dp, h->insts, time, h->d_state, h->d_time, h->d_ee);
+        if (run_num % gait_opt_freq == 0 && run_num > 0) {
+            // instances without a ready gradient get the plain update through the same 10-candidate batch (zero step)
+            if (line_search_core(g, true)) return -1;
+            hipLaunchKernelGGL(srbm_k_gait_ready, dim3((h->batch + 63) / 64), dim3(64), 0, h->stream, h->dp, g->valid, g->lp_status, g->ready, 0);
+        } else if ((run_num + 1) % gait_opt_freq == 0 && run_num > 0) {
+            if (launch_step(h)) return -1;
+            if (gait_opt_core(g)) return -1;
+        } else {
+            if (launch_step(h)) return -1;
+            hipLaunchKernelGGL(srbm_k_gait_ready, dim3((h->batch + 63) / 64), dim3(64), 0, h->stream, h->dp, g->valid, g->lp_status, g->ready, 0);
+        }
+        HIPCHK(hipGetLastError());
+    }
     return 0;
 }
 /* status / stats of the candidates of the last line search: status[batch][10], iters[batch][10] (diagnostic) */

@@ -300,6 +300,20 @@ class BatchGaitOptimizer:
         m._chk(self.L.srbm_gait_get_gradient(self.g, _d(g), _i(valid)))
         return g, valid
 
+    def optimize_contact_times(self, time):
+        m = self.mpc
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(time, dtype=np.float64), (m.batch,)))
+        m._chk(self.L.srbm_gait_optimize_contact_times(self.g, _d(t)))
+
+    def lp_result(self):
+        m = self.mpc
+        st = np.zeros(m.batch, np.int32); pr = np.zeros(m.batch)
+        m._chk(self.L.srbm_gait_get_lp_result(self.g, _i(st), _d(pr)))
+        return st, pr
+
+    def rti_advance(self, first_run_num, steps, gait_opt_freq):
+        self.mpc._chk(self.L.srbm_gait_rti_advance(self.g, int(first_run_num), int(steps), int(gait_opt_freq)))
+
     def set_step(self, step):
         a = np.zeros((self.mpc.batch, self.NV))
         st = np.asarray(step, dtype=np.float64)

@@ -86,6 +86,12 @@ int srbm_gait_get_sensitivity(srbm_gait* g, double* d, int ld);
  * valid[batch] = 0 where the reference refuses (last QP not Solved, mpc.cpp:1048) -- may be NULL */
 int srbm_gait_compute_gradient(srbm_gait* g);
 int srbm_gait_get_gradient(srbm_gait* g, double* dHdth, int* valid);
+/* GaitOptimizer::OptimizeContactTimes (gait_optimizer.cpp:185-364): the LP  min dHdth' s  over the polytope of
+ * gait_optimizer.cpp:410-534 at time[batch]; the step stays on the device for the line search.
+ * lp_status[batch]: 0 solved, 1 iteration limit, 2 numerical failure (the reference throws "Bad gait optimization
+ * solve"); pred_red[batch] = -dHdth' s (gait_optimizer.cpp:352-356) */
+int srbm_gait_optimize_contact_times(srbm_gait* g, const double* time);
+int srbm_gait_get_lp_result(srbm_gait* g, int* lp_status, double* pred_red);
 /* step of the outer problem (result of OptimizeContactTimes, or supplied by the caller): step[batch][32] */
 int srbm_gait_set_step(srbm_gait* g, const double* step);
 int srbm_gait_get_step(srbm_gait* g, double* step);
@@ -94,6 +100,13 @@ int srbm_gait_get_step(srbm_gait* g, double* step);
  * candidate (cost / n, primal-infeasible ones excluded, index 0 if all are) is installed with
  * MPC::SetWarmStartTrajectory.  imin[batch], costs[batch][10] may be NULL. */
 int srbm_gait_line_search(srbm_gait* g, const double* state, const double* init_time, const double* ee, int* imin, double* costs);
+/* The MPC loop of the controller with the gait step folded in (controllers/mpc_controller.cpp:320-346), device
+ * resident and open loop like srbm_rti_advance (test/gait_opt_playground.cpp:113-126): for run_num = first_run_num ...
+ *   run_num % gait_opt_freq == 0, run_num > 0 : GaitOptimizer::LineSearch where a gradient is ready (plain update elsewhere)
+ *   (run_num + 1) % gait_opt_freq == 0        : MPC::GetRealTimeUpdate, then MPCController::GaitOpt (gradient + LP)
+ *   otherwise                                 : MPC::GetRealTimeUpdate
+ * Asynchronous on the batch's stream; srbm_synchronize(h) to wait. */
+int srbm_gait_rti_advance(srbm_gait* g, int first_run_num, int steps, int gait_opt_freq);
 /* solver status / error bits of the candidates of the last line search: status[batch*10], err[batch*10] */
 int srbm_gait_get_candidate_status(srbm_gait* g, int* status, int* err);
 

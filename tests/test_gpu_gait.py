@@ -157,3 +157,75 @@ def test_cost_gradient_wrt_contact_times_matches_oracle(cfgname, nsteps):
     assert np.array_equal(gg[0], gg[1])
     assert np.all(gg[0, nv:] == 0)
     assert np.abs(gg[0, :nv] - go).max() <= 1e-3 * max(1.0, np.abs(go).max()), (gg[0, :nv], go)
+
+
+@pytest.mark.parametrize('cfgname,nsteps', [('a1_configuration', 3), ('a1_configuration', 8), ('a1_gait_opt_config', 2),
+                                            ('a1_config_distr_rejection', 4)])
+def test_contact_time_lp_matches_oracle(cfgname, nsteps):
+    """a15: the LP over the contact-time step.  Same gradient in (the oracle's), so the two LP solvers are compared on
+    identical data: equal optimal value, feasible step, and equal entries wherever the cost coefficient is not ~0
+    (a zero coefficient leaves that entry undetermined; interior-point codes then return different interior points)."""
+    cfg, g, o, state, ee, t = run_pair(cfgname, nsteps)
+    go = o.gait_gradient()
+    assert go is not None
+    step_o, new_o = o.gait_optimize(t)
+    nv = len(go)
+    gait = host.BatchGaitOptimizer(g)
+    gait.compute_gradient()
+    gg, valid = gait.gradient()
+    gait.optimize_contact_times(t)
+    st, pred = gait.lp_result()
+    step = gait.step()
+    assert np.all(st == 0)
+    assert np.all(np.abs(step[0, :nv]) <= 1 + 1e-8) and np.all(step[0, nv:] == 0)
+    val_g, val_o = gg[0, :nv] @ step[0, :nv], go @ step_o[:nv]
+    assert abs(val_g - val_o) <= 2e-3 * max(1.0, abs(val_o))
+    assert abs(pred[0] + val_g) <= 1e-9 * max(1.0, abs(val_g))
+    big = np.abs(go) > 1e-3 * np.abs(go).max()
+    assert np.abs(step[0, :nv] - step_o[:nv])[big].max() <= 1e-4
+
+
+@pytest.mark.parametrize('cfgname,runs,knot_tol', [('a1_gait_opt_config', 12, 1e-9), ('a1_configuration', 7, 1e-2)])
+def test_controller_loop_with_gait_step(cfgname, runs, knot_tol):
+    """The controller's MPC loop with the bilevel step every 5th iteration (controllers/mpc_controller.cpp:320-346),
+    device-resident (srbm_gait_rti_advance) against the same protocol on the oracle.  For a1_configuration the run
+    stops after the first line search: a contact time beyond the horizon has a zero gradient, the LP leaves its step
+    undetermined (the two LP codes return 0.935 and 0.928), and once that knot enters the horizon the two runs are two
+    equally valid different gait schedules; until then its only trace is in the knot table (knot_tol)."""
+    F = 5
+    cfg = load_config(cfgname)
+    s0 = np.array(cfg['srb_init'], float)
+    g = host.BatchMPC(cfg, 2)
+    g.set_state_trajectory_warm_start(s0)
+    g.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+    o = OracleMPC(cfg)
+    o.set_warmstart(s0)
+    g.create_initial_run(s0, EE0); o.initial_run(s0, EE0)
+    gait = host.BatchGaitOptimizer(g)
+    dt = cfg['integrator_dt']
+    ready = False
+    n_ls = 0
+    for run in range(runs):
+        t = run * dt
+        state = o.states()[1]
+        ee = np.array([[o.ee_value(e, 1, c, t) for c in range(3)] for e in range(4)])
+        if run % F == 0 and run > 0 and ready:
+            o.gait_line_search(state, t, ee); ready = False; n_ls += 1
+        elif (run + 1) % F == 0 and run > 0:
+            o.rti(state, t, ee)
+            ready = o.gait_gradient() is not None
+            if ready:
+                o.gait_optimize(t)
+        else:
+            o.rti(state, t, ee); ready = False
+        gait.rti_advance(run, 1, F); g.synchronize()
+        st, err = g.status()
+        assert np.all(err == 0)
+        tr = g.trajectory_states()
+        assert np.array_equal(tr[0], tr[1])
+        assert relerr(tr[0], o.states()) < REL_TOL, run
+        kg = g.knots(0)
+        for e in range(4):
+            ko = o.knots(e)
+            assert kg['nk'][e] == ko['K'] and np.abs(kg['times'][e, :ko['K']] - ko['times']).max() <= knot_tol, (run, e)
+    assert n_ls >= 1
