@@ -608,6 +608,24 @@ int srbm_gait_get_candidate_status(srbm_gait* g, int* status, int* err) {
     return srbm_get_status(g->ls, status, err);
 }
 
+// MPC::AdjustForCurrentContacts (mpc.cpp:1195-1203): time[batch], in_contact[batch][4]
+int srbm_adjust_for_current_contacts(srbm_batch* h, const double* time, const int* in_contact) {
+    if (!h || !time || !in_contact) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    int* dc = nullptr;
+    const size_t B = h->batch;
+    HIPCHK(hipMalloc(&dc, sizeof(int) * 4 * B));
+    HIPCHK(hipMemcpyAsync(dc, in_contact, sizeof(int) * 4 * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_time, time, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+    const int tot = h->batch * SRBM_NEE;
+    hipLaunchKernelGGL(srbm_k_adjust_for_current_contacts, dim3((tot + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts, h->d_time, dc);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipFree(dc));
+    return 0;
+}
+
 int srbm_enable_kernel_timing(srbm_batch* h, int max_launches) {
     if (!h || max_launches < 0) return fail("bad arguments");
     HIPCHK(hipSetDevice(h->device));

@@ -183,6 +183,11 @@ class BatchMPC:
         assert a.ndim == 3 and a.shape[0] == self.batch and a.shape[1] == 4
         self._chk(self.L.srbm_update_contact_times(self.h, _d(a), a.shape[2]))
 
+    def adjust_for_current_contacts(self, time, in_contact):
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(time, dtype=np.float64), (self.batch,)))
+        c = np.ascontiguousarray(np.broadcast_to(np.asarray(in_contact, dtype=np.int32), (self.batch, 4)))
+        self._chk(self.L.srbm_adjust_for_current_contacts(self.h, _d(t), _i(c)))
+
     # ---- measurement aids ----
     def enable_kernel_timing(self, max_launches):
         self._chk(self.L.srbm_enable_kernel_timing(self.h, int(max_launches)))

@@ -64,6 +64,10 @@ void* srbm_stream(srbm_batch* h);            /* hipStream_t the kernels are laun
  * number of contact knots of every foot */
 int srbm_update_contact_times(srbm_batch* h, const double* times, int max_contacts);
 
+/* MPC::AdjustForCurrentContacts (mpc/mpc.cpp:1195-1203) -> EndEffectorSplines::SetToTouchdown
+ * (mpc/spline/end_effector_splines.cpp:1042-1060): time[batch], in_contact[batch][4] (0/1 per foot) */
+int srbm_adjust_for_current_contacts(srbm_batch* h, const double* time, const int* in_contact);
+
 /* ---- bilevel (gait) step: mpc::GaitOptimizer (mpc/include/gait_optimizer.h:20-170) for every instance of a batch ----
  * Contact-time vectors are laid out as in the reference's QP vector (gait_optimizer.cpp:395-408): foot after foot,
  * counts[batch][4] contact times per foot, row stride SRBM_GAIT_NV = 32 doubles per instance. */

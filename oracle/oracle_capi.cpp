@@ -177,6 +177,16 @@ int orc_mpc_set_contact_times(void* p, int ee_count, const int* counts, const do
     } catch (const std::exception& e) { h->err = e.what(); return -1; }
     return 0;
 }
+// MPC::AdjustForCurrentContacts (mpc.cpp:1195-1203)
+int orc_mpc_adjust_for_current_contacts(void* p, double time, const int* in_contact4) {
+    auto* h = static_cast<OrcMPC*>(p);
+    try {
+        std::vector<bool> c(4);
+        for (int i = 0; i < 4; i++) c[i] = in_contact4[i] != 0;
+        h->mpc->AdjustForCurrentContacts(time, c);
+    } catch (const std::exception& e) { h->err = e.what(); return -1; }
+    return 0;
+}
 double orc_mpc_ee_value(void* p, int ee, int is_position, int coord, double t) {
     auto* h = static_cast<OrcMPC*>(p);
     return h->mpc->GetTrajectory().EE(ee).ValueAt(is_position ? orc::Position : orc::Force, coord, t);

@@ -192,6 +192,10 @@ class OracleMPC:
         flat = np.ascontiguousarray(np.concatenate([np.asarray(t, float) for t in times_per_ee]))
         return self._chk(self.L.orc_mpc_set_contact_times(self.h, len(times_per_ee), _i(counts), _d(flat)))
 
+    def adjust_for_current_contacts(self, t, in_contact):
+        c = np.ascontiguousarray(in_contact, dtype=np.int32)
+        return self._chk(self.L.orc_mpc_adjust_for_current_contacts(self.h, C.c_double(t), _i(c)))
+
     def ee_value(self, ee, is_position, coord, t):
         return self.L.orc_mpc_ee_value(self.h, ee, int(is_position), coord, C.c_double(t))
 

@@ -241,6 +241,37 @@ def test_updated_contact_times_parity():
     assert relerr(g.qp_solution()[0, :n], o.x()) < REL_TOL
 
 
+def test_early_touchdown_adjustment_parity():
+    """a17: MPC::AdjustForCurrentContacts -- a foot reported in contact 50 ms before its planned touch-down has that
+    knot (and the stance-interior knots) re-timed; knot tables bit-exact, the following RTI step within tolerance"""
+    cfg = load_config()
+    g, o, s0 = make_pair(cfg)
+    g.create_initial_run(s0, EE0); o.initial_run(s0, EE0)
+    dt = cfg['integrator_dt']
+    changed = False
+    for i in range(8):
+        t = i * dt
+        state = o.states()[1]
+        ee = np.array([[o.ee_value(e, 1, c, t) for c in range(3)] for e in range(4)])
+        # feet whose next touch-down is within 70 ms are declared "already down"
+        contact = [1, 1, 1, 1]
+        before = [o.knots(e)['times'].copy() for e in range(4)]
+        o.adjust_for_current_contacts(t, contact)
+        g.adjust_for_current_contacts(t, contact)
+        kg = g.knots(0)
+        for e in range(4):
+            ko = o.knots(e)
+            assert kg['nk'][e] == ko['K'] and np.array_equal(kg['times'][e, :ko['K']], ko['times']), (i, e)
+            changed |= not np.array_equal(before[e], ko['times'])
+        o.rti(state, t, ee)
+        g.get_real_time_update(state, t, ee)
+        st, err = g.status()
+        assert err[0] == 0 and status_class(st[0]) == status_class(o.stats()['status'])
+        n = o.sizes()['n']
+        assert relerr(g.qp_solution()[0, :n], o.x()) < REL_TOL, i
+    assert changed      # the scenario did exercise SetToTouchdown
+
+
 def test_short_horizon_config_a():
     cfg = load_config(num_nodes=10)       # Config A of BASELINE.json: N=10 plumbing case
     g, o, s0 = make_pair(cfg)
