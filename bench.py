@@ -113,6 +113,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='instances per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--gait-steps', type=int, default=30,
+                    help='extra, separately timed segment: controller loop with the bilevel (gait) step every 5th iteration (0 = skip)')
     args = ap.parse_args()
 
     import torch
@@ -161,6 +163,34 @@ def main():
     k3_ms, k3_launches = mpc.kernel_timing()
     it1, fl1 = mpc.work_counters()
     st, err = mpc.status()
+
+    # ---- second segment (Config C): the same batch continues with the gait step every 5th iteration ----
+    gait_stats = None
+    if args.gait_steps > 0:
+        FREQ = 5
+        gait = host.BatchGaitOptimizer(mpc)
+        first = args.warmup + args.steps
+        first += (-first) % FREQ + 1                 # start right after a multiple of FREQ: every block of 5 = 3 RTI + (RTI + GaitOpt) + LineSearch
+        n_ls = sum(1 for r in range(first, first + args.gait_steps) if r % FREQ == 0)
+        n_go = sum(1 for r in range(first, first + args.gait_steps) if (r + 1) % FREQ == 0)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        gait.rti_advance(first, args.gait_steps, FREQ)
+        mpc.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el_g = max_over_ranks(time.perf_counter() - tg)
+        stg, errg = mpc.status()
+        n_all = B * world
+        solves = n_all * ((args.gait_steps - n_ls) + 10 * n_ls)      # a line search is 10 RTI solves per instance
+        gait_stats = {'workload': 'Config C protocol on the Config-B batch: gait step every 5th iteration (gradient + LP, then 10-candidate line search)',
+                      'steps': args.gait_steps, 'gait_opt_steps': n_go, 'line_search_steps': n_ls,
+                      'rti_solves_per_s_incl_line_search': solves / el_g, 'gait_steps_per_s': n_all * n_ls / el_g,
+                      'ms_per_step': 1e3 * el_g / args.gait_steps,
+                      'statuses_after': {int(k): int(v) for k, v in zip(*np.unique(stg, return_counts=True))}, 'err_bits': int(np.bitwise_or.reduce(errg))}
     ok = bool(np.all(err == 0) and np.all((st == 0) | (st == 1) | (st == 2)))
     n_inst = B * world
     value = n_inst * args.steps / elapsed
@@ -184,6 +214,8 @@ def main():
                          'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': None,
                          'avg_launch_ms': k3_avg_s * 1e3, 'algorithmic_flops_per_launch': flops_per_launch},
         }
+        if gait_stats is not None:
+            out['gait'] = gait_stats
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(out))
