@@ -141,7 +141,8 @@ static int launch_step(srbm_batch* h) {
     hipLaunchKernelGGL(srbm_k2_condense, dim3(B), dim3(K2_THREADS), 0, h->stream, h->dp, h->insts, h->works);
     const bool tm = h->timing && h->ev_used < h->ev_start.size();
     if (tm) HIPCHK(hipEventRecord(h->ev_start[h->ev_used], h->stream));
-    hipLaunchKernelGGL(srbm_k3_ipm, dim3(B), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works);
+    if (h->hp.N <= K3_SHORT_N) hipLaunchKernelGGL(srbm_k3_ipm, dim3(B), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works);
+    else hipLaunchKernelGGL(srbm_k3_ipm_long, dim3(B), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works);
     if (tm) { HIPCHK(hipEventRecord(h->ev_stop[h->ev_used], h->stream)); h->ev_used++; }
     hipLaunchKernelGGL(srbm_k4_update, dim3(B), dim3(K4_THREADS), 0, h->stream, h->dp, h->insts, h->works);
     HIPCHK(hipGetLastError());
@@ -160,7 +161,40 @@ int srbm_debug_get_profile(srbm_batch* h, int inst, double* out16) {
     HIPCHK(hipMemcpy(out16, reinterpret_cast<const char*>(h->works + inst) + offsetof(SrbmWork, prof), sizeof(double) * 16, hipMemcpyDeviceToHost));
     return 0;
 }
+int srbm_debug_get_profile2(srbm_batch* h, int inst, double* out64) {
+    if (!h || inst < 0 || inst >= h->batch) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out64, reinterpret_cast<const char*>(h->works + inst) + offsetof(SrbmWork, prof2), sizeof(double) * 64, hipMemcpyDeviceToHost));
+    return 0;
+}
 // unit-test hook for the dense building blocks: Cholesky of `count` packed lower-triangular n x n matrices, one workgroup each
+__global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_solve(int n, const double* __restrict__ Min, const double* __restrict__ rhs,
+                                                               double* __restrict__ xout, double* __restrict__ Xout, int* __restrict__ ticks) {
+    extern __shared__ double dbg_smem2[];
+    const int np = n * (n + 1) / 2;
+    double* M = dbg_smem2;
+    double* panel = dbg_smem2 + (size_t)SRBM_NUMAX * (SRBM_NUMAX + 1) / 2;
+    double* xv = panel + DN_PANEL_DOUBLES;
+    double* tv = xv + SRBM_NUMAX;
+    const double* src = Min + (size_t)blockIdx.x * np;
+    for (int e = threadIdx.x; e < np; e += DN_THREADS) M[e] = src[e];
+    for (int e = threadIdx.x; e < n; e += DN_THREADS) xv[e] = rhs[(size_t)blockIdx.x * n + e];
+    __syncthreads();
+    DnTiles T;
+    int nreg = 0;
+    dn_load_packed(T, M, n);
+    dn_cholesky(T, M, n, panel, &nreg);
+    chol_invert_diag_blocks(M, n);
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    dn_trtri(M, n);
+    const long long t1 = (long long)__builtin_amdgcn_s_memtime();
+    dn_solve_inv(M, n, xv, tv);
+    const long long t2 = (long long)__builtin_amdgcn_s_memtime();
+    for (int e = threadIdx.x; e < n; e += DN_THREADS) xout[(size_t)blockIdx.x * n + e] = xv[e];
+    for (int e = threadIdx.x; e < np; e += DN_THREADS) Xout[(size_t)blockIdx.x * np + e] = M[e];
+    if (threadIdx.x == 0) { ticks[2 * blockIdx.x] = (int)(t1 - t0); ticks[2 * blockIdx.x + 1] = (int)(t2 - t1); }
+}
 __global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_cholesky(int n, const double* __restrict__ Min, double* __restrict__ Lout, int* __restrict__ nreg_out) {
     extern __shared__ double dbg_smem[];
     const int np = n * (n + 1) / 2;
@@ -177,6 +211,26 @@ __global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_cholesky(int n, const
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
     for (int e = threadIdx.x; e < np; e += DN_THREADS) Lout[(size_t)blockIdx.x * np + e] = M[e];
     if (threadIdx.x == 0) nreg_out[blockIdx.x] = nreg | ((int)min((long long)0x7fffff, (t1 - t0) >> 4) << 8);   // bits 8..: ticks / 16 (diagnostic)
+}
+/* unit-test hook: x = M^-1 rhs through Cholesky + explicit inverse of the factor; X_packed = L^-1; ticks[2*count] */
+int srbm_debug_solve(int n, int count, const double* M_packed, const double* rhs, double* x, double* X_packed, int* ticks) {
+    if (n <= 0 || n > SRBM_NUMAX || count <= 0 || !M_packed || !rhs || !x || !X_packed || !ticks) return fail("bad arguments");
+    const size_t np = (size_t)n * (n + 1) / 2, bytes = np * count * sizeof(double), vb = (size_t)n * count * sizeof(double);
+    double *dM = nullptr, *dX = nullptr, *dr = nullptr, *dx = nullptr; int* dt = nullptr;
+    HIPCHK(hipMalloc(&dM, bytes)); HIPCHK(hipMalloc(&dX, bytes)); HIPCHK(hipMalloc(&dr, vb)); HIPCHK(hipMalloc(&dx, vb));
+    HIPCHK(hipMalloc(&dt, sizeof(int) * 2 * count));
+    HIPCHK(hipMemcpy(dM, M_packed, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dr, rhs, vb, hipMemcpyHostToDevice));
+    const size_t lds = ((size_t)SRBM_NUMAX * (SRBM_NUMAX + 1) / 2 + DN_PANEL_DOUBLES + 2 * SRBM_NUMAX) * sizeof(double);
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k_debug_solve), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(srbm_k_debug_solve, dim3(count), dim3(DN_THREADS), lds, 0, n, dM, dr, dx, dX, dt);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(x, dx, vb, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(X_packed, dX, bytes, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ticks, dt, sizeof(int) * 2 * count, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(dM)); HIPCHK(hipFree(dX)); HIPCHK(hipFree(dr)); HIPCHK(hipFree(dx)); HIPCHK(hipFree(dt));
+    return 0;
 }
 int srbm_debug_cholesky(int n, int count, const double* M_packed, double* L_packed, int* nreg) {
     if (n <= 0 || n > SRBM_NUMAX || count <= 0 || !M_packed || !L_packed || !nreg) return fail("bad arguments");
@@ -237,6 +291,7 @@ int srbm_batch_create(srbm_batch** out, int batch, const srbm_mpc_info* info, co
     HIPCHK(hipMemsetAsync(h->works, 0, sizeof(SrbmWork) * (size_t)batch, h->stream));
     h->k3_lds = srbm_k3_lds_bytes(p.N);
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_ipm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_ipm_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
     if (upload_params(h)) { delete h; return -1; }
     hipLaunchKernelGGL(srbm_k_init, dim3((batch + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts);
     HIPCHK(hipGetLastError());

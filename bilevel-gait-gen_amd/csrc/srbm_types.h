@@ -108,6 +108,7 @@ typedef struct SrbmWork {
     double s[SRBM_MMAX];
     double Ms[SRBM_HPACK];                        /* gait step: H + G' diag(lambda/s) G of the last solution (srbm_k3_normal_matrix) */
     double w0[SRBM_MIMAX];                        /* IPM: unit weight of the row/cost-scaled problem, e_r^2 / c (kernel 3 scratch) */
+    double prof2[64];                             /* diagnostic builds only: fine-grained stamps (K3_FINE) */
     double prof[16];                              /* diagnostic builds only (-DSRBM_PROFILE): cycles per IPM phase */
     double dbg[4 * 64];
     double dbg2[4 * 32];                          /* diagnostic builds only: worst refinement row (index, s, lambda, e2) */                           /* diagnostic builds only: per-iteration (mu, alpha_aff, alpha, gap_rel) */

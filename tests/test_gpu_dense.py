@@ -69,3 +69,31 @@ def test_mfma_cholesky_reports_indefinite_input():
     M = np.eye(n); M[17, 17] = -1.0
     (L,), nreg = device_cholesky([M])
     assert nreg[0] == 1
+
+
+def device_solve(mats, rhs):
+    lib = host.lib()
+    n = mats[0].shape[0]
+    inp = np.ascontiguousarray(np.stack([pack(M) for M in mats])); r = np.ascontiguousarray(np.stack(rhs))
+    x = np.zeros_like(r); X = np.zeros_like(inp); ticks = np.zeros(2 * len(mats), np.int32)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    rc = lib.srbm_debug_solve(n, len(mats), dp(inp), dp(r), dp(x), dp(X), ticks.ctypes.data_as(C.POINTER(C.c_int)))
+    assert rc == 0, lib.srbm_last_error().decode()
+    device_solve.ticks = ticks.reshape(-1, 2)
+    return x, [unpack(v, n) for v in X]
+
+
+@pytest.mark.parametrize('n', [1, 5, 16, 17, 33, 64, 100, 120, 128, 129, 144, 157, 160])
+def test_explicit_factor_inverse_and_solve(n):
+    """X = L^-1 by MFMA tile products, then x = X'(X b): against numpy"""
+    rng = np.random.default_rng(100 + n)
+    mats, rhs = [], []
+    for _ in range(2):
+        A = rng.standard_normal((n, n + 3))
+        mats.append(A @ A.T + 0.5 * np.eye(n)); rhs.append(rng.standard_normal(n))
+    x, Xs = device_solve(mats, rhs)
+    for M, b, xv, X in zip(mats, rhs, x, Xs):
+        L = np.linalg.cholesky(M)
+        assert np.abs(X @ L - np.eye(n)).max() <= 1e-10 * np.linalg.cond(L)
+        xr = np.linalg.solve(M, b)
+        assert np.abs(xv - xr).max() <= 1e-9 * max(1.0, np.abs(xr).max()) * np.linalg.cond(M) ** 0.5
