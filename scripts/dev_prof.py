@@ -22,7 +22,7 @@ for n, v in zip(names, out):
 
 out2 = np.zeros(64)
 gb.L.srbm_debug_get_profile2(gb.h, 0, out2.ctypes.data_as(C.POINTER(C.c_double)))
-names2 = {0: 'other->eval', 1: 'eval: force samples', 2: 'eval: dense rows', 3: 'other->gt', 4: 'gt: cs', 5: 'gt: dense rows', 6: 'gt: sparse gather', 7: 'other->M', 8: 'M force blocks', 9: 'M pos blocks', 10: 'M dense + factor + invert', 20: '  tiles <- LDS', 21: '  cholesky', 22: '  invert diag blocks', 23: '  trtri'}
+names2 = {0: 'other->eval', 1: 'eval: force samples', 2: 'eval: dense rows', 3: 'other->gt', 4: 'gt: cs', 5: 'gt: dense rows', 6: 'gt: sparse gather', 7: 'other->M', 8: 'M force blocks', 9: 'M pos blocks', 10: 'M dense + factor + invert', 20: '  tiles <- LDS', 21: '  cholesky', 22: '  invert diag blocks', 23: '  trtri', 24: '  rank-2 update (MFMA)'}
 print('fine stamps (accumulated over all RTI steps of this process; shares of their sum):')
 tot2 = out2.sum()
 for k, n in names2.items():
