@@ -106,6 +106,16 @@ def cpu_baseline(cfg, seconds_budget=20.0):
             'sample': '%d Config-B instances x 30 RTI steps after 10 cold-start solves each, oracle/ (C++ -O2, 1 thread)' % inst}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE need two separate rocprofv3
+    runs, so the figure is read from the committed summary of those runs, profiles/r01/k3_pmc_traffic.json; None if absent)"""
+    path = os.path.join(ROOT, 'profiles', 'r01', 'k3_pmc_traffic.json')
+    try:
+        return float(json.load(open(path))['hbm_bytes_per_launch'])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -211,7 +221,7 @@ def main():
                        'all_solved': ok, 'statuses': {int(k): int(v) for k, v in zip(*np.unique(status_all, return_counts=True))},
                        'mean_ipm_iterations': (it1 - it0) / max(1, (hi - lo) * args.steps)},
             'roofline': {'bound': 'mfma', 'kernel': 'srbm_k3_ipm', 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': None,
+                         'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': pmc_traffic(),
                          'avg_launch_ms': k3_avg_s * 1e3, 'algorithmic_flops_per_launch': flops_per_launch},
         }
         if gait_stats is not None:
