@@ -79,6 +79,22 @@ def config_b_instance(cfg, b):
     return state, ee
 
 
+def config_d_instance(cfg, b):
+    """instance b of Config D: apps/a1_config_distr_rejection.yaml values (N=50, dt=0.02); the file's
+    single push becomes a distribution -- lin-mom xy ~ N(0, 2.5^2) truncated at 3 sigma, yaw ang-mom ~ N(0, 0.2^2), seed 777 + b"""
+    rng = np.random.Generator(np.random.MT19937(777 + b))
+    def tnorm(sig):
+        while True:
+            v = rng.normal(0.0, sig)
+            if abs(v) <= 3 * sig:
+                return v
+    state = np.array(cfg['srb_init'], float)
+    state[3] += tnorm(2.5); state[4] += tnorm(2.5)
+    state[12] += rng.normal(0.0, 0.2)
+    ee = np.array([[0.2, 0.2, 0], [0.2, -0.2, 0], [-0.2, 0.2, 0], [-0.2, -0.2, 0]], float)      # test/simulation_mpc.cpp:104-108
+    return state, ee
+
+
 def cpu_baseline(cfg, seconds_budget=20.0):
     """The oracle (CPU restatement of the reference algorithm, oracle/) timed on this box's host cores: a bounded sample
     of the SAME workload -- instances 0.. of Config B, 10 cold-start solves each (untimed) then 30 timed RTI steps --
@@ -123,6 +139,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='instances per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', choices=['B', 'D'], default='B',
+                    help='B (default, the metric\'s configuration): 256 instances/GPU, N=20; D: 512 instances/GPU, N=50, push distribution')
     ap.add_argument('--gait-steps', type=int, default=30,
                     help='extra, separately timed segment: controller loop with the bilevel (gait) step every 5th iteration (0 = skip)')
     args = ap.parse_args()
@@ -141,10 +159,11 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world)
 
-    cfg = host.load_config('a1_configuration')
-    B = args.batch
+    cfg = host.load_config('a1_configuration' if args.workload == 'B' else 'a1_config_distr_rejection')
+    B = args.batch if args.workload == 'B' else (512 if args.batch == BATCH_PER_GPU else args.batch)
+    make_instance = config_b_instance if args.workload == 'B' else config_d_instance
     lo, hi = shard_range(B * world, rank, world)            # this rank's instances of the global batch
-    states, ees = zip(*[config_b_instance(cfg, b) for b in range(lo, hi)])
+    states, ees = zip(*[make_instance(cfg, b) for b in range(lo, hi)])
     states, ees = np.array(states), np.array(ees).reshape(hi - lo, 12)
 
     mpc = host.BatchMPC(cfg, hi - lo, device=local_rank)
@@ -196,7 +215,7 @@ def main():
         stg, errg = mpc.status()
         n_all = B * world
         solves = n_all * ((args.gait_steps - n_ls) + 10 * n_ls)      # a line search is 10 RTI solves per instance
-        gait_stats = {'workload': 'Config C protocol on the Config-B batch: gait step every 5th iteration (gradient + LP, then 10-candidate line search)',
+        gait_stats = {'workload': 'Config C protocol on the same batch: gait step every 5th iteration (gradient + LP, then 10-candidate line search)',
                       'steps': args.gait_steps, 'gait_opt_steps': n_go, 'line_search_steps': n_ls,
                       'rti_solves_per_s_incl_line_search': solves / el_g, 'gait_steps_per_s': n_all * n_ls / el_g,
                       'ms_per_step': 1e3 * el_g / args.gait_steps,
@@ -211,22 +230,24 @@ def main():
         flops_per_launch = (fl1 - fl0) / max(1, k3_launches)
         achieved = flops_per_launch / k3_avg_s / 1e12 if k3_avg_s > 0 else 0.0
         out = {
-            'metric': 'MPC RTI iterations/sec (batched A1 SRBM, N=20)',
+            'metric': 'MPC RTI iterations/sec (batched A1 SRBM, N=%d)' % cfg['num_nodes'],
             'value': value, 'unit': 'it/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'Config B: %d A1 SRBM MPC instances per GPU, N=20, dt=0.05, a1_configuration.yaml values, '
-                                   '10 cold-start solves then open-loop RTI steps (state := node 1)' % B,
-                       'batch_per_gpu': B, 'global_batch': n_inst, 'num_nodes': 20, 'parallelism': 'instances sharded x%d' % world,
+            'config': {'workload': ('Config B: %d A1 SRBM MPC instances per GPU, N=20, dt=0.05, a1_configuration.yaml values, '
+                                    '10 cold-start solves then open-loop RTI steps (state := node 1)' % B) if args.workload == 'B' else
+                                   ('Config D: %d A1 SRBM MPC instances per GPU, N=50, dt=0.02, a1_config_distr_rejection.yaml values, push '
+                                    'distribution on the initial momentum, 10 cold-start solves then open-loop RTI steps' % B),
+                       'batch_per_gpu': B, 'global_batch': n_inst, 'num_nodes': cfg['num_nodes'], 'parallelism': 'instances sharded x%d' % world,
                        'all_solved': ok, 'statuses': {int(k): int(v) for k, v in zip(*np.unique(status_all, return_counts=True))},
                        'mean_ipm_iterations': (it1 - it0) / max(1, (hi - lo) * args.steps)},
-            'roofline': {'bound': 'mfma', 'kernel': 'srbm_k3_ipm', 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': pmc_traffic(),
+            'roofline': {'bound': 'mfma', 'kernel': 'srbm_k3_ipm' if cfg['num_nodes'] <= 22 else 'srbm_k3_ipm_long', 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': pmc_traffic() if args.workload == 'B' else None,
                          'avg_launch_ms': k3_avg_s * 1e3, 'algorithmic_flops_per_launch': flops_per_launch},
         }
         if gait_stats is not None:
             out['gait'] = gait_stats
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'B':
             out['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(out))
     if world > 1:
