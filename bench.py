@@ -122,12 +122,14 @@ def cpu_baseline(cfg, seconds_budget=20.0):
             'sample': '%d Config-B instances x 30 RTI steps after 10 cold-start solves each, oracle/ (C++ -O2, 1 thread)' % inst}
 
 
-def pmc_traffic():
+def pmc_traffic(steps):
     """HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE need two separate rocprofv3
-    runs, so the figure is read from the committed summary of those runs, profiles/r01/k3_pmc_traffic.json; None if absent)"""
+    runs, so the figure is read from the committed summary of those runs, profiles/r01/k3_pmc_traffic.json, and scaled to the
+    number of RTI steps of this launch; None if absent)"""
     path = os.path.join(ROOT, 'profiles', 'r01', 'k3_pmc_traffic.json')
     try:
-        return float(json.load(open(path))['hbm_bytes_per_launch'])
+        d = json.load(open(path))
+        return float(d['hbm_bytes_per_launch']) * steps / float(d['steps_per_launch'])
     except Exception:
         return None
 
@@ -175,7 +177,7 @@ def main():
     rec = torch.zeros((hi - lo, RESULT_LD), dtype=torch.float64, device='cuda')
 
     it0, fl0 = mpc.work_counters()
-    mpc.enable_kernel_timing(args.steps)
+    mpc.enable_kernel_timing(4)          # the K timed steps are ONE launch of the fused RTI kernel
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -241,8 +243,8 @@ def main():
                        'batch_per_gpu': B, 'global_batch': n_inst, 'num_nodes': cfg['num_nodes'], 'parallelism': 'instances sharded x%d' % world,
                        'all_solved': ok, 'statuses': {int(k): int(v) for k, v in zip(*np.unique(status_all, return_counts=True))},
                        'mean_ipm_iterations': (it1 - it0) / max(1, (hi - lo) * args.steps)},
-            'roofline': {'bound': 'mfma', 'kernel': 'srbm_k3_ipm' if cfg['num_nodes'] <= 22 else 'srbm_k3_ipm_long', 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': pmc_traffic() if args.workload == 'B' else None,
+            'roofline': {'bound': 'mfma', 'kernel': 'srbm_rti_fused' if cfg['num_nodes'] <= 22 else 'srbm_rti_fused_long', 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': pmc_traffic(args.steps) if args.workload == 'B' else None,
                          'avg_launch_ms': k3_avg_s * 1e3, 'algorithmic_flops_per_launch': flops_per_launch},
         }
         if gait_stats is not None:

@@ -29,6 +29,7 @@ struct srbm_batch {
     // optional HIP-event timing of the dominant kernel (srbm_k3_ipm) on the launch stream
     bool timing = false;
     std::vector<hipEvent_t> ev_start, ev_stop;
+    std::vector<int> ev_steps;        // RTI steps covered by each timed launch (1 for the stand-alone IPM kernel)
     size_t ev_used = 0;
 };
 
@@ -94,8 +95,8 @@ __global__ void srbm_k_warm_start(const SrbmParams* __restrict__ Pp, SrbmInst* _
 }
 
 // inputs of the next open-loop iteration (test/gait_opt_playground.cpp:113-126)
-__global__ void srbm_k_next_inputs(const SrbmParams* __restrict__ Pp, const SrbmInst* __restrict__ insts, double time,
-                                   double* __restrict__ state_out, double* __restrict__ time_out, double* __restrict__ ee_out) {
+__device__ __forceinline__ void srbm_next_inputs_body(const SrbmParams* __restrict__ Pp, const SrbmInst* __restrict__ insts, double time,
+                                                      double* __restrict__ state_out, double* __restrict__ time_out, double* __restrict__ ee_out) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const SrbmInst& I = insts[b];
     if (tid < 13) state_out[(size_t)b * 13 + tid] = I.states[13 + tid];
@@ -109,6 +110,45 @@ __global__ void srbm_k_next_inputs(const SrbmParams* __restrict__ Pp, const Srbm
         const double z = srbm_posz_value(f, time, Pp->swing_height, Pp->foot_offset, &err);
         ee_out[(size_t)b * 12 + ee * 3] = xy[0]; ee_out[(size_t)b * 12 + ee * 3 + 1] = xy[1]; ee_out[(size_t)b * 12 + ee * 3 + 2] = z;
     }
+}
+__global__ void srbm_k_next_inputs(const SrbmParams* __restrict__ Pp, const SrbmInst* __restrict__ insts, double time,
+                                   double* __restrict__ state_out, double* __restrict__ time_out, double* __restrict__ ee_out) {
+    srbm_next_inputs_body(Pp, insts, time, state_out, time_out, ee_out);
+}
+
+// The whole open-loop protocol of test/gait_opt_playground.cpp:113-126 in ONE launch: every workgroup walks its own
+// instance through `steps` RTI iterations (next inputs -> assemble -> condense -> IPM -> update), the phases separated by
+// workgroup barriers only.  No grid-wide synchronisation between the phases or the steps: an instance that needs 18 IPM
+// iterations in a step does not wait for the one that needs 25, the imbalance averages out over the steps.  The
+// working sets of kernels 1, 2 and 4 are windows of the IPM kernel's dynamic LDS.
+template <int RPT>
+__device__ __forceinline__ void srbm_rti_fused_body(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works,
+                                                    int first_index, int steps, double* __restrict__ d_state, double* __restrict__ d_time,
+                                                    double* __restrict__ d_ee) {
+    static_assert(K1_THREADS == K3_THREADS && K2_THREADS == K3_THREADS && K4_THREADS == K3_THREADS, "the fused kernel runs all phases with one block size");
+    for (int s = 0; s < steps; s++) {
+        const double time = (first_index + s) * Pp->dt;
+        srbm_next_inputs_body(Pp, insts, time, d_state, d_time, d_ee);
+        __syncthreads();
+        srbm_k1_assemble_body(Pp, insts, works, d_state, d_time, d_ee, *reinterpret_cast<K1Shared*>(k3_smem));
+        __syncthreads();
+        srbm_k2_condense_body(Pp, insts, works, *reinterpret_cast<K2Shared*>(k3_smem));
+        __syncthreads();
+        srbm_k3_body<0, RPT>(Pp, insts, works);
+        __syncthreads();
+        srbm_k4_update_body(Pp, insts, works, *reinterpret_cast<K4Shared*>(k3_smem));
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(K3_THREADS) void srbm_rti_fused(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works,
+                                                             int first_index, int steps, double* __restrict__ d_state, double* __restrict__ d_time,
+                                                             double* __restrict__ d_ee) {
+    srbm_rti_fused_body<K3_RPT_SHORT>(Pp, insts, works, first_index, steps, d_state, d_time, d_ee);
+}
+__global__ __launch_bounds__(K3_THREADS) void srbm_rti_fused_long(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works,
+                                                                  int first_index, int steps, double* __restrict__ d_state, double* __restrict__ d_time,
+                                                                  double* __restrict__ d_ee) {
+    srbm_rti_fused_body<K3_RPT>(Pp, insts, works, first_index, steps, d_state, d_time, d_ee);
 }
 
 // EndEffectorSplines::SetContactTimes (end_effector_splines.cpp:860-892) for every foot of every instance
@@ -143,7 +183,7 @@ static int launch_step(srbm_batch* h) {
     if (tm) HIPCHK(hipEventRecord(h->ev_start[h->ev_used], h->stream));
     if (h->hp.N <= K3_SHORT_N) hipLaunchKernelGGL(srbm_k3_ipm, dim3(B), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works);
     else hipLaunchKernelGGL(srbm_k3_ipm_long, dim3(B), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works);
-    if (tm) { HIPCHK(hipEventRecord(h->ev_stop[h->ev_used], h->stream)); h->ev_used++; }
+    if (tm) { HIPCHK(hipEventRecord(h->ev_stop[h->ev_used], h->stream)); h->ev_steps[h->ev_used] = 1; h->ev_used++; }
     hipLaunchKernelGGL(srbm_k4_update, dim3(B), dim3(K4_THREADS), 0, h->stream, h->dp, h->insts, h->works);
     HIPCHK(hipGetLastError());
     return 0;
@@ -292,6 +332,8 @@ int srbm_batch_create(srbm_batch** out, int batch, const srbm_mpc_info* info, co
     h->k3_lds = srbm_k3_lds_bytes(p.N);
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_ipm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_ipm_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_rti_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_rti_fused_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
     if (upload_params(h)) { delete h; return -1; }
     hipLaunchKernelGGL(srbm_k_init, dim3((batch + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts);
     HIPCHK(hipGetLastError());
@@ -389,8 +431,28 @@ int srbm_rti_advance(srbm_batch* h, int first_index, int steps) {
     if (!h || steps < 0) return fail("bad arguments");
     HIPCHK(hipSetDevice(h->device));
     if (upload_params(h)) return -1;
+    if (steps == 0) return 0;
+    // one launch for all steps (double time = i*info.integrator_dt, gait_opt_playground.cpp:84, is formed on the device)
+    const bool tm = h->timing && h->ev_used < h->ev_start.size();
+    if (tm) HIPCHK(hipEventRecord(h->ev_start[h->ev_used], h->stream));
+    if (h->hp.N <= K3_SHORT_N)
+        hipLaunchKernelGGL(srbm_rti_fused, dim3(h->batch), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works, first_index, steps,
+                           h->d_state, h->d_time, h->d_ee);
+    else
+        hipLaunchKernelGGL(srbm_rti_fused_long, dim3(h->batch), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works, first_index, steps,
+                           h->d_state, h->d_time, h->d_ee);
+    if (tm) { HIPCHK(hipEventRecord(h->ev_stop[h->ev_used], h->stream)); h->ev_steps[h->ev_used] = steps; h->ev_used++; }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// the same protocol, one kernel launch per phase and step (grid-wide synchronisation between the phases); kept for
+// A/B measurements against the fused kernel
+int srbm_rti_advance_unfused(srbm_batch* h, int first_index, int steps) {
+    if (!h || steps < 0) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
     for (int i = 0; i < steps; i++) {
-        const double time = (first_index + i) * h->hp.dt;      // double time = i*info.integrator_dt (gait_opt_playground.cpp:84)
+        const double time = (first_index + i) * h->hp.dt;
         hipLaunchKernelGGL(srbm_k_next_inputs, dim3(h->batch), dim3(64), 0, h->stream, h->dp, h->insts, time, h->d_state, h->d_time, h->d_ee);
         if (launch_step(h)) return -1;
     }
@@ -687,7 +749,7 @@ int srbm_enable_kernel_timing(srbm_batch* h, int max_launches) {
     while ((int)h->ev_start.size() < max_launches) {
         hipEvent_t a, b;
         HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-        h->ev_start.push_back(a); h->ev_stop.push_back(b);
+        h->ev_start.push_back(a); h->ev_stop.push_back(b); h->ev_steps.push_back(0);
     }
     h->ev_used = 0; h->timing = max_launches > 0;
     return 0;

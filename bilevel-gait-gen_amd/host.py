@@ -172,6 +172,9 @@ class BatchMPC:
     def rti_advance(self, first_index, steps):
         self._chk(self.L.srbm_rti_advance(self.h, int(first_index), int(steps)))
 
+    def rti_advance_unfused(self, first_index, steps):
+        self._chk(self.L.srbm_rti_advance_unfused(self.h, int(first_index), int(steps)))
+
     def synchronize(self):
         self._chk(self.L.srbm_synchronize(self.h))
 

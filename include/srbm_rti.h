@@ -57,6 +57,8 @@ int srbm_get_real_time_update_dev(srbm_batch* h, const double* state_dev, const 
  * state := node 1 of the previous trajectory, foot locations := previous trajectory at t, t_i = (first_index+i)*dt.
  * No host round trip between iterations.  Asynchronous; srbm_synchronize() to wait. */
 int srbm_rti_advance(srbm_batch* h, int first_index, int steps);
+/* same protocol with one kernel launch per phase and step (A/B measurements against the fused kernel) */
+int srbm_rti_advance_unfused(srbm_batch* h, int first_index, int steps);
 int srbm_synchronize(srbm_batch* h);
 void* srbm_stream(srbm_batch* h);            /* hipStream_t the kernels are launched on */
 

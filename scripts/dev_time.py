@@ -1,19 +1,21 @@
-"""Developer script: time the device-resident RTI protocol (no oracle)."""
-import importlib.util, os, sys, time
+"""Developer script: wall time of the device-resident RTI protocol, fused kernel vs one launch per phase (no oracle)."""
+import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-spec = importlib.util.spec_from_file_location('srbm_host', os.path.join(ROOT, 'bilevel-gait-gen_amd', 'host.py'))
-host = importlib.util.module_from_spec(spec); spec.loader.exec_module(host)
-cfg = host.load_config(sys.argv[1] if len(sys.argv) > 1 else 'a1_configuration')
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-K = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-s0 = np.array(cfg['srb_init'], float)
-ee = np.array([[0.2, 0.2, 0], [0.2, -0.2, 0], [-0.2, 0.2, 0], [-0.2, -0.2, 0]], float)
-gb = host.BatchMPC(cfg, B); gb.set_state_trajectory_warm_start(s0); gb.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
-gb.create_initial_run(s0, ee)
-gb.rti_advance(0, 3); gb.synchronize()
-t0 = time.time()
-gb.rti_advance(3, K); gb.synchronize()
-el = time.time() - t0
-st, err = gb.status()
-print('batch %d: %d RTI steps in %.4f s -> %.1f it/s (%.3f ms/step) status %s err %s iters %.1f' % (B, K, el, B * K / el, 1e3 * el / K, np.unique(st), np.unique(err), gb.stats()[:, 4].mean()))
+sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
+from srbm_loader import host
+import bench
+cfg = host.load_config()
+B = 256
+states, ees = zip(*[bench.config_b_instance(cfg, b) for b in range(B)])
+states, ees = np.array(states), np.array(ees).reshape(B, 12)
+for mode in ('fused', 'unfused', 'fused', 'unfused'):
+    g = host.BatchMPC(cfg, B); g.set_state_trajectory_warm_start(states); g.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+    g.create_initial_run(states, ees)
+    adv = g.rti_advance if mode == 'fused' else g.rti_advance_unfused
+    adv(0, 5); g.synchronize()
+    t0 = time.perf_counter()
+    adv(5, 100); g.synchronize()
+    el = time.perf_counter() - t0
+    it, fl = g.work_counters()
+    print(mode, '%.3f ms/step  %.0f it/s' % (1e3 * el / 100, B * 100 / el), 'statuses', np.unique(g.status()[0], return_counts=True))
