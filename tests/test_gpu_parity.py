@@ -217,6 +217,28 @@ def test_device_resident_protocol_equals_host_driven_loop():
     assert relerr(xa[0, :n], o.x()) < REL_TOL
 
 
+def test_fused_kernel_equals_one_launch_per_phase():
+    """srbm_rti_advance (all phases of all steps in one launch, workgroup barriers only) against the same protocol with
+    one launch per phase: bit-identical trajectories, knot tables and QP solutions"""
+    cfg = load_config()
+    B = 8
+    states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees).reshape(B, 12)
+    res = []
+    for fused in (True, False):
+        g = host.BatchMPC(cfg, B)
+        g.set_state_trajectory_warm_start(states)
+        g.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+        g.create_initial_run(states, ees)
+        (g.rti_advance if fused else g.rti_advance_unfused)(0, 7)
+        g.synchronize()
+        st, err = g.status()
+        assert np.all(err == 0)
+        res.append((g.trajectory_states(), g.qp_solution(), g.sizes(), st, g.knots(3)['times']))
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
 def test_updated_contact_times_parity():
     """MPC::UpdateContactTimes (mpc.cpp:1085-1088 -> EndEffectorSplines::SetContactTimes :860-892) then an RTI step."""
     cfg = load_config()
