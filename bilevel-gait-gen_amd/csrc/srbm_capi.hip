@@ -329,7 +329,10 @@ int srbm_batch_create(srbm_batch** out, int batch, const srbm_mpc_info* info, co
     HIPCHK(hipMalloc(&h->d_time, sizeof(double) * (size_t)batch));
     HIPCHK(hipMalloc(&h->d_ee, sizeof(double) * 12 * (size_t)batch));
     HIPCHK(hipMemsetAsync(h->works, 0, sizeof(SrbmWork) * (size_t)batch, h->stream));
-    h->k3_lds = srbm_k3_lds_bytes(p.N);
+    // the IPM kernel gets the whole LDS of a CU: what its fixed map leaves over holds the dense state rows (K3Smem::sig_row)
+    h->k3_lds = K3_LDS_LAUNCH_BYTES;
+    if (srbm_k3_lds_bytes(p.N) > h->k3_lds) { delete h; return fail("srbm_batch_create: LDS map exceeds 160 KB"); }
+    p.lds_doubles = (int)(h->k3_lds / sizeof(double));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_ipm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_ipm_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_rti_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
