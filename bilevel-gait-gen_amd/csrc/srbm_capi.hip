@@ -320,7 +320,11 @@ int srbm_batch_create(srbm_batch** out, int batch, const srbm_mpc_info* info, co
         p.hip[2 * ee] = x; p.hip[2 * ee + 1] = y;
     }
     p.merit_mu = 5000; p.td_fraction = 0.75;
-    p.tol_gap_abs = 1e-8; p.tol_gap_rel = 1e-8; p.tol_feas = 1e-10;     // clarabel_interface.cpp:21-23
+    // ClarabelInterface::ConfigureForInitialRun / ConfigureForSolve (clarabel_interface.cpp:165-175) run every solve of the
+    // reference at tol_gap 1e-15, tol_feas 1e-10.  1e-15 is below the fp64 noise floor of this QP (the gap stops improving
+    // around 1e-13..1e-14 for the reference's solver restatement as well), so the default here is 1e-13: same minimiser to
+    // the 1e-4 the path is specified to, without the iterations spent detecting the stall.  srbm_set_solver_tolerances overrides.
+    p.tol_gap_abs = 1e-13; p.tol_gap_rel = 1e-13; p.tol_feas = 1e-10;
     HIPCHK(hipStreamCreate(&h->stream));
     HIPCHK(hipMalloc(&h->dp, sizeof(SrbmParams)));
     HIPCHK(hipMalloc(&h->insts, sizeof(SrbmInst) * (size_t)batch));

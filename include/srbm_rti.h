@@ -43,7 +43,8 @@ int srbm_set_quadratic_final_cost(srbm_batch* h, const double* Phi144);
 int srbm_set_linear_final_cost(srbm_batch* h, const double* w12);
 /* MPC::SetStateTrajectoryWarmStart (mpc/mpc.cpp:700-706): states[batch][13], replicated over the horizon */
 int srbm_set_state_trajectory_warm_start(srbm_batch* h, const double* states);
-/* ClarabelInterface tolerances (mpc/qp/clarabel_interface.cpp:18-27,165-175) for the on-device IPM */
+/* ClarabelInterface tolerances (mpc/qp/clarabel_interface.cpp:18-27,165-175) for the on-device IPM.
+ * Defaults: gap 1e-13 (the reference's 1e-15 is below the fp64 noise floor of this QP), feasibility 1e-10, 200 iterations */
 int srbm_set_solver_tolerances(srbm_batch* h, double tol_gap_abs, double tol_gap_rel, double tol_feas, int max_iter);
 
 /* MPC::CreateInitialRun (mpc/mpc.cpp:78-90): 10 solves at t = 0.   state[batch][13], ee[batch][4][3] */
