@@ -816,6 +816,14 @@ int srbm_get_status(srbm_batch* h, int* status, int* err) {
     for (int b = 0; b < h->batch; b++) { status[b] = v[b].status; if (err) err[b] = v[b].err; }
     return 0;
 }
+// QP objective at the raw QP minimiser (the "QP Cost" column of MPC::PrintStatLineToFile, mpc.cpp:989): cost[batch]
+int srbm_get_qp_cost(srbm_batch* h, double* cost) {
+    if (!h || !cost) return fail("bad arguments");
+    std::vector<SrbmInst> v;
+    if (fetch_insts(h, v)) return -1;
+    for (int b = 0; b < h->batch; b++) cost[b] = v[b].qp_cost;
+    return 0;
+}
 int srbm_get_stats(srbm_batch* h, double* stats) {
     if (!h || !stats) return fail("bad arguments");
     std::vector<SrbmInst> v;

@@ -61,6 +61,34 @@ def load_config(name='a1_configuration', **overrides):
     return cfg
 
 
+def load_yaml_config(yaml_path, model_constants):
+    """The reference's own configuration files (apps/*.yaml, keys as parsed in /root/reference/test/simulation_mpc.cpp:55-89
+    and controllers/mpc_controller.cpp:27-67) -> the cfg dict of BatchMPC.  model_constants: dict with 'mass', 'Ir' (3x3)
+    and 'hip_xy' (FL FR RL RR) -- what the reference asks pinocchio for at construction."""
+    import yaml
+    y = yaml.safe_load(open(yaml_path))
+    keys = ['num_nodes', 'integrator_dt', 'friction_coef', 'force_bound', 'swing_height', 'foot_offset', 'ee_box_size', 'force_cost',
+            'Q_srbd_diag', 'srb_init']
+    missing = [k for k in keys if k not in y]
+    if missing:
+        raise KeyError('%s: missing keys %s' % (yaml_path, missing))
+    cfg = {k: y[k] for k in keys}
+    if 'srb_target' in y:
+        cfg['srb_target'] = y['srb_target']
+    else:       # configurations that predate srb_target give x_des / y_des (apps/a1_gait_opt_config.yaml:126-129)
+        tgt = list(y['srb_init']); tgt[0] = y.get('x_des', tgt[0]); tgt[1] = y.get('y_des', tgt[1]); cfg['srb_target'] = tgt
+    cfg['gait_opt_freq'] = y.get('gait_opt_freq', 5)
+    cfg['mass'] = float(model_constants['mass'])
+    cfg['Ir'] = np.asarray(model_constants['Ir'], float).reshape(3, 3).tolist()
+    cfg['hip_xy'] = np.asarray(model_constants['hip_xy'], float).reshape(4, 2).tolist()
+    cfg['source'] = os.path.basename(yaml_path)
+    return cfg
+
+
+SOLVE_TYPE_NAMES = {0: 'Solved', 1: 'Solved Inacc', 2: 'Max Iter', 3: 'P - Infeasible', 4: 'D - Infeasible', 5: 'P - Infeasible Inacc',
+                    6: 'D - Infeasible Inacc', 7: 'Unsolved'}      # MPC::PrintStatLineToFile, mpc.cpp:944-972
+
+
 def _d(a):
     return a.ctypes.data_as(_dp)
 
@@ -191,6 +219,31 @@ class BatchMPC:
         c = np.ascontiguousarray(np.broadcast_to(np.asarray(in_contact, dtype=np.int32), (self.batch, 4)))
         self._chk(self.L.srbm_adjust_for_current_contacts(self.h, _d(t), _i(c)))
 
+    # ---- the reference's statistics log ----
+    def print_stat_header(self, fh):
+        """header block of MPC::PrintStatLineToFile (mpc.cpp:901-939), same field widths"""
+        cw, tw = 15, 150
+        c = self.cfg
+        fh.write('-' * tw + '\n' + ' ' * (tw // 2 - 7) + 'MPC Statistics\n')
+        fh.write('Number of nodes: %d\nMPC time step: %g\nForce bounds: %g\nEnd Effector box size: %g %g\n' %
+                 (self.N, c['integrator_dt'], c['force_bound'], c['ee_box_size'][0], c['ee_box_size'][1]))
+        fh.write('Force cost: %g\nFoot offset: %g\nSwing height: %g\n' % (c['force_cost'], c['foot_offset'], c['swing_height']))
+        fh.write('-' * tw + '\n')
+        cols = ['Solve #', 'Time (ms)', 'Constraints', 'Step Norm', 'Alpha', 'Cost', 'Merit', 'Merit dd', 'Solve Type', 'QP Cost']
+        fh.write(''.join(n.rjust(cw) for n in cols) + '\n' + '-' * tw + '\n')
+
+    def print_stat_line(self, fh, solve_number, time_ms, inst=0):
+        """one table row of MPC::PrintStatLineToFile (mpc.cpp:974-989) for instance `inst` from the last solve.  Merit =
+        cost + mu * L1 dynamics defect (mpc.cpp:749-757, mu = 5000); the directional derivative is not kept on the device
+        and is printed as '-'."""
+        cw = 15
+        st, err = self.status()
+        s = self.stats()[inst]
+        merit = s[1] + 5000.0 * s[2]
+        vals = ['%d' % solve_number, '%g' % time_ms, '%g' % s[2], '%g' % s[3], '%g' % s[0], '%g' % s[1], '%g' % merit, '-',
+                SOLVE_TYPE_NAMES.get(int(st[inst]), 'Other'), '%g' % self.qp_cost()[inst]]
+        fh.write(''.join(v.rjust(cw) for v in vals) + '\n')
+
     # ---- measurement aids ----
     def enable_kernel_timing(self, max_launches):
         self._chk(self.L.srbm_enable_kernel_timing(self.h, int(max_launches)))
@@ -222,6 +275,11 @@ class BatchMPC:
     def stats(self):
         a = np.zeros((self.batch, 8))
         self._chk(self.L.srbm_get_stats(self.h, _d(a)))
+        return a
+
+    def qp_cost(self):
+        a = np.zeros(self.batch)
+        self._chk(self.L.srbm_get_qp_cost(self.h, _d(a)))
         return a
 
     def qp_solution(self):

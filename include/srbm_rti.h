@@ -124,6 +124,8 @@ int srbm_get_sizes(srbm_batch* h, int* sizes);
 int srbm_get_status(srbm_batch* h, int* status, int* err);
 /* stats[batch][8] = alpha, cost (GetCost), L1 dynamics defect, step norm, qp iterations, res_primal, res_dual, gap_rel */
 int srbm_get_stats(srbm_batch* h, double* stats);
+/* objective of the QP at its raw minimiser, cost[batch] (the "QP Cost" column of MPC::PrintStatLineToFile, mpc/mpc.cpp:974-989) */
+int srbm_get_qp_cost(srbm_batch* h, double* cost);
 /* MPC::GetQPSolution (prev_qp_sol after the line search), x[batch][ld]; ld >= n_max */
 int srbm_get_qp_solution(srbm_batch* h, double* x, int ld);
 int srbm_get_raw_qp_minimiser(srbm_batch* h, double* x, int ld);

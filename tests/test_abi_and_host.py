@@ -108,3 +108,22 @@ rc = [p.wait() for p in procs]
 sys.exit(max(rc))
 ''' % code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_reference_yaml_configuration_loads(tmp_path):
+    """host.load_yaml_config reads the reference's own YAML keys (test/simulation_mpc.cpp:55-89); checked on a YAML written
+    from the committed JSON configuration (the reference's files do not travel)"""
+    import json, yaml
+    from srbm_loader import host
+    cfg = host.load_config('a1_configuration')
+    y = {k: cfg[k] for k in ['num_nodes', 'integrator_dt', 'friction_coef', 'force_bound', 'swing_height', 'foot_offset', 'ee_box_size',
+                             'force_cost', 'Q_srbd_diag', 'srb_init', 'srb_target', 'gait_opt_freq']}
+    p = tmp_path / 'a1.yaml'
+    p.write_text(yaml.safe_dump(y))
+    c2 = host.load_yaml_config(str(p), dict(mass=cfg['mass'], Ir=cfg['Ir'], hip_xy=cfg['hip_xy']))
+    for k in y:
+        assert c2[k] == cfg[k], k
+    assert np.allclose(c2['Ir'], cfg['Ir']) and np.allclose(c2['hip_xy'], cfg['hip_xy'])
+    (tmp_path / 'bad.yaml').write_text(yaml.safe_dump({'num_nodes': 20}))
+    with pytest.raises(KeyError):
+        host.load_yaml_config(str(tmp_path / 'bad.yaml'), dict(mass=1, Ir=np.eye(3), hip_xy=np.zeros((4, 2))))

@@ -294,6 +294,30 @@ def test_early_touchdown_adjustment_parity():
     assert changed      # the scenario did exercise SetToTouchdown
 
 
+def test_statistics_log_line_format(tmp_path):
+    """MPC::PrintStatLineToFile (mpc.cpp:901-989): 10 right-aligned columns of width 15, values of the last solve"""
+    cfg = load_config()
+    g, o, s0 = make_pair(cfg)
+    g.create_initial_run(s0, EE0); o.initial_run(s0, EE0)
+    state = o.states()[1]
+    ee = np.array([[o.ee_value(e, 1, c, 0.0) for c in range(3)] for e in range(4)])
+    o.rti(state, 0.0, ee); g.get_real_time_update(state, 0.0, ee)     # a step with a real Armijo decision
+    p = tmp_path / 'mpc_log.txt'
+    with open(p, 'w') as fh:
+        g.print_stat_header(fh)
+        g.print_stat_line(fh, 10, 1.25)
+    lines = open(p).read().splitlines()
+    assert lines[0] == '-' * 150 and 'MPC Statistics' in lines[1] and lines[2] == 'Number of nodes: 20'
+    row = lines[-1]
+    assert len(row) == 150
+    cols = [row[15 * i:15 * (i + 1)].strip() for i in range(10)]
+    so = o.stats()
+    assert cols[0] == '10' and cols[8] in ('Solved', 'Solved Inacc')
+    assert abs(float(cols[4]) - so['alpha']) < 1e-12
+    assert abs(float(cols[5]) - so['cost']) <= 1e-4 * max(1.0, abs(so['cost']))
+    assert abs(float(cols[2]) - so['eq_violation']) <= 1e-4 * max(1.0, abs(so['eq_violation'])) + 1e-9
+
+
 def test_short_horizon_config_a():
     cfg = load_config(num_nodes=10)       # Config A of BASELINE.json: N=10 plumbing case
     g, o, s0 = make_pair(cfg)
