@@ -121,6 +121,24 @@ __global__ void srbm_k_next_inputs(const SrbmParams* __restrict__ Pp, const Srbm
 // workgroup barriers only.  No grid-wide synchronisation between the phases or the steps: an instance that needs 18 IPM
 // iterations in a step does not wait for the one that needs 25, the imbalance averages out over the steps.  The
 // working sets of kernels 1, 2 and 4 are windows of the IPM kernel's dynamic LDS.
+// Each phase is an out-of-line function: its registers are allocated for that phase alone (inlined into one body, values of
+// one phase were kept live -- spilled -- across the others and out of the step loop).
+__device__ __noinline__ void srbm_phase_inputs_assemble(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works,
+                                                        double time, double* __restrict__ d_state, double* __restrict__ d_time, double* __restrict__ d_ee) {
+    srbm_next_inputs_body(Pp, insts, time, d_state, d_time, d_ee);
+    __syncthreads();
+    srbm_k1_assemble_body(Pp, insts, works, d_state, d_time, d_ee, *reinterpret_cast<K1Shared*>(k3_smem));
+}
+__device__ __noinline__ void srbm_phase_condense(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works) {
+    srbm_k2_condense_body(Pp, insts, works, *reinterpret_cast<K2Shared*>(k3_smem));
+}
+template <int RPT>
+__device__ __noinline__ void srbm_phase_ipm(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works) {
+    srbm_k3_body<0, RPT>(Pp, insts, works);
+}
+__device__ __noinline__ void srbm_phase_update(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works) {
+    srbm_k4_update_body(Pp, insts, works, *reinterpret_cast<K4Shared*>(k3_smem));
+}
 template <int RPT>
 __device__ __forceinline__ void srbm_rti_fused_body(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works,
                                                     int first_index, int steps, double* __restrict__ d_state, double* __restrict__ d_time,
@@ -128,15 +146,13 @@ __device__ __forceinline__ void srbm_rti_fused_body(const SrbmParams* __restrict
     static_assert(K1_THREADS == K3_THREADS && K2_THREADS == K3_THREADS && K4_THREADS == K3_THREADS, "the fused kernel runs all phases with one block size");
     for (int s = 0; s < steps; s++) {
         const double time = (first_index + s) * Pp->dt;
-        srbm_next_inputs_body(Pp, insts, time, d_state, d_time, d_ee);
+        srbm_phase_inputs_assemble(Pp, insts, works, time, d_state, d_time, d_ee);
         __syncthreads();
-        srbm_k1_assemble_body(Pp, insts, works, d_state, d_time, d_ee, *reinterpret_cast<K1Shared*>(k3_smem));
+        srbm_phase_condense(Pp, insts, works);
         __syncthreads();
-        srbm_k2_condense_body(Pp, insts, works, *reinterpret_cast<K2Shared*>(k3_smem));
+        srbm_phase_ipm<RPT>(Pp, insts, works);
         __syncthreads();
-        srbm_k3_body<0, RPT>(Pp, insts, works);
-        __syncthreads();
-        srbm_k4_update_body(Pp, insts, works, *reinterpret_cast<K4Shared*>(k3_smem));
+        srbm_phase_update(Pp, insts, works);
         __syncthreads();
     }
 }

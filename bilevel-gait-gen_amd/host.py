@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libsrbm_rti.so')
+LIB_PATH = os.environ.get('SRBM_RTI_LIB', os.path.join(HERE, 'libsrbm_rti.so'))   # override: A/B builds of scripts/dev_ab.py
 CONFIG_DIR = os.path.join(HERE, 'configs')
 
 _dp = C.POINTER(C.c_double)
