@@ -123,20 +123,20 @@ __global__ void srbm_k_next_inputs(const SrbmParams* __restrict__ Pp, const Srbm
 // working sets of kernels 1, 2 and 4 are windows of the IPM kernel's dynamic LDS.
 // Each phase is an out-of-line function: its registers are allocated for that phase alone (inlined into one body, values of
 // one phase were kept live -- spilled -- across the others and out of the step loop).
-__device__ __noinline__ void srbm_phase_inputs_assemble(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works,
+static __device__ __noinline__ void srbm_phase_inputs_assemble(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works,
                                                         double time, double* __restrict__ d_state, double* __restrict__ d_time, double* __restrict__ d_ee) {
     srbm_next_inputs_body(Pp, insts, time, d_state, d_time, d_ee);
     __syncthreads();
     srbm_k1_assemble_body(Pp, insts, works, d_state, d_time, d_ee, *reinterpret_cast<K1Shared*>(k3_smem));
 }
-__device__ __noinline__ void srbm_phase_condense(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works) {
+static __device__ __noinline__ void srbm_phase_condense(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works) {
     srbm_k2_condense_body(Pp, insts, works, *reinterpret_cast<K2Shared*>(k3_smem));
 }
 template <int RPT>
-__device__ __noinline__ void srbm_phase_ipm(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works) {
+static __device__ __noinline__ void srbm_phase_ipm(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works) {
     srbm_k3_body<0, RPT>(Pp, insts, works);
 }
-__device__ __noinline__ void srbm_phase_update(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works) {
+static __device__ __noinline__ void srbm_phase_update(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works) {
     srbm_k4_update_body(Pp, insts, works, *reinterpret_cast<K4Shared*>(k3_smem));
 }
 template <int RPT>
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_solve(int n, const do
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
     dn_trtri(M, n);
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
-    dn_solve_inv(M, n, xv, tv);
+    dn_solve_inv(0, n, (int)(xv - dbg_smem2), (int)(tv - dbg_smem2));
     const long long t2 = (long long)__builtin_amdgcn_s_memtime();
     for (int e = threadIdx.x; e < n; e += DN_THREADS) xout[(size_t)blockIdx.x * n + e] = xv[e];
     for (int e = threadIdx.x; e < np; e += DN_THREADS) Xout[(size_t)blockIdx.x * np + e] = M[e];
