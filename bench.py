@@ -143,6 +143,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', choices=['B', 'D'], default='B',
                     help='B (default, the metric\'s configuration): 256 instances/GPU, N=20; D: 512 instances/GPU, N=50, push distribution')
+    ap.add_argument('--closed-loop-steps', type=int, default=20,
+                    help='extra, separately timed segment: closed-loop rollouts against the SRBM plant with pushes (0 = skip)')
     ap.add_argument('--gait-steps', type=int, default=30,
                     help='extra, separately timed segment: controller loop with the bilevel (gait) step every 5th iteration (0 = skip)')
     args = ap.parse_args()
@@ -222,6 +224,39 @@ def main():
                       'rti_solves_per_s_incl_line_search': solves / el_g, 'gait_steps_per_s': n_all * n_ls / el_g,
                       'ms_per_step': 1e3 * el_g / args.gait_steps,
                       'statuses_after': {int(k): int(v) for k, v in zip(*np.unique(stg, return_counts=True))}, 'err_bits': int(np.bitwise_or.reduce(errg))}
+    # ---- third segment: closed-loop rollouts, plant = SRBM dynamics under the current trajectory + one push per instance ----
+    cl_stats = None
+    if args.closed_loop_steps > 0:
+        SUB = 10
+        cl = host.BatchMPC(cfg, hi - lo, device=local_rank)
+        cl.set_state_trajectory_warm_start(states)
+        cl.create_initial_run(states, ees)
+        cl.plant_set_state(states)
+        rng = np.random.default_rng(777 + lo)
+        imp = np.zeros((hi - lo, 6))
+        imp[:, 0:2] = np.clip(rng.normal(0.0, 2.5, (hi - lo, 2)), -7.5, 7.5)       # lin-mom xy ~ N(0, 2.5^2), truncated at 3 sigma (Config D)
+        imp[:, 5] = rng.normal(0.0, 0.2, hi - lo)                                   # yaw-rate ang-mom ~ N(0, 0.2^2)
+        cl.plant_set_push(np.full(hi - lo, 2.5 * cfg['integrator_dt']), imp)
+        cl.closed_loop_advance(0, 2, SUB, True)
+        cl.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        cl.closed_loop_advance(2, args.closed_loop_steps, SUB, True)
+        cl.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el_c = max_over_ranks(time.perf_counter() - tc)
+        stc, errc = cl.status()
+        cl_stats = {'workload': 'closed loop on a fresh copy of the batch: plant = SRBM dynamics (explicit Euler, %d sub-steps per step) under the current '
+                                'trajectory, one push per instance at t = 2.5 dt (Config D distribution)' % SUB,
+                    'steps': args.closed_loop_steps, 'rti_iterations_per_s': B * world * args.closed_loop_steps / el_c,
+                    'ms_per_step': 1e3 * el_c / args.closed_loop_steps,
+                    'statuses_after': {int(k): int(v) for k, v in zip(*np.unique(stc, return_counts=True))}, 'err_bits': int(np.bitwise_or.reduce(errc)),
+                    'plant_finite': bool(np.all(np.isfinite(cl.plant_state())))}
+        del cl
     ok = bool(np.all(err == 0) and np.all((st == 0) | (st == 1) | (st == 2)))
     n_inst = B * world
     value = n_inst * args.steps / elapsed
@@ -249,6 +284,8 @@ def main():
         }
         if gait_stats is not None:
             out['gait'] = gait_stats
+        if cl_stats is not None:
+            out['closed_loop'] = cl_stats
         if world == 1 and not args.no_cpu_baseline and args.workload == 'B':
             out['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(out))

@@ -9,6 +9,7 @@
 
 #include "srbm_k4_update.hiph"
 #include "srbm_gait.hiph"
+#include "srbm_plant.hiph"
 #include "../../include/srbm_rti.h"
 
 static thread_local std::string g_err;
@@ -22,6 +23,8 @@ struct srbm_batch {
     SrbmInst* insts = nullptr;
     SrbmWork* works = nullptr;
     double *d_state = nullptr, *d_time = nullptr, *d_ee = nullptr;
+    double *d_plant = nullptr, *d_push_time = nullptr, *d_push_impulse = nullptr;   // closed-loop harness (srbm_plant.hiph)
+    bool push_set = false;
     hipStream_t stream = nullptr;
     bool owns_stream = true;
     size_t k3_lds = 0;
@@ -124,8 +127,11 @@ __global__ void srbm_k_next_inputs(const SrbmParams* __restrict__ Pp, const Srbm
 // Each phase is an out-of-line function: its registers are allocated for that phase alone (inlined into one body, values of
 // one phase were kept live -- spilled -- across the others and out of the step loop).
 static __device__ __noinline__ void srbm_phase_inputs_assemble(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works,
-                                                        double time, double* __restrict__ d_state, double* __restrict__ d_time, double* __restrict__ d_ee) {
-    srbm_next_inputs_body(Pp, insts, time, d_state, d_time, d_ee);
+                                                        double time, double* __restrict__ d_state, double* __restrict__ d_time, double* __restrict__ d_ee,
+                                                        double* __restrict__ plant, const double* __restrict__ push_time,
+                                                        const double* __restrict__ push_impulse, int substeps, int advance_time) {
+    if (plant) srbm_plant_inputs_body(Pp, insts, time, substeps, advance_time, plant, push_time, push_impulse, d_state, d_time, d_ee);
+    else srbm_next_inputs_body(Pp, insts, time, d_state, d_time, d_ee);
     __syncthreads();
     srbm_k1_assemble_body(Pp, insts, works, d_state, d_time, d_ee, *reinterpret_cast<K1Shared*>(k3_smem));
 }
@@ -139,14 +145,19 @@ static __device__ __noinline__ void srbm_phase_ipm(const SrbmParams* __restrict_
 static __device__ __noinline__ void srbm_phase_update(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works) {
     srbm_k4_update_body(Pp, insts, works, *reinterpret_cast<K4Shared*>(k3_smem));
 }
+// closed-loop mode of the fused kernel: plant != nullptr (srbm_plant.hiph)
+struct SrbmPlantArgs {
+    double* plant; const double* push_time; const double* push_impulse;
+    int substeps, advance_time;
+};
 template <int RPT>
 __device__ __forceinline__ void srbm_rti_fused_body(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works,
                                                     int first_index, int steps, double* __restrict__ d_state, double* __restrict__ d_time,
-                                                    double* __restrict__ d_ee) {
+                                                    double* __restrict__ d_ee, const SrbmPlantArgs pl) {
     static_assert(K1_THREADS == K3_THREADS && K2_THREADS == K3_THREADS && K4_THREADS == K3_THREADS, "the fused kernel runs all phases with one block size");
     for (int s = 0; s < steps; s++) {
         const double time = (first_index + s) * Pp->dt;
-        srbm_phase_inputs_assemble(Pp, insts, works, time, d_state, d_time, d_ee);
+        srbm_phase_inputs_assemble(Pp, insts, works, time, d_state, d_time, d_ee, pl.plant, pl.push_time, pl.push_impulse, pl.substeps, pl.advance_time);
         __syncthreads();
         srbm_phase_condense(Pp, insts, works);
         __syncthreads();
@@ -158,13 +169,13 @@ __device__ __forceinline__ void srbm_rti_fused_body(const SrbmParams* __restrict
 }
 __global__ __launch_bounds__(K3_THREADS) void srbm_rti_fused(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works,
                                                              int first_index, int steps, double* __restrict__ d_state, double* __restrict__ d_time,
-                                                             double* __restrict__ d_ee) {
-    srbm_rti_fused_body<K3_RPT_SHORT>(Pp, insts, works, first_index, steps, d_state, d_time, d_ee);
+                                                             double* __restrict__ d_ee, const SrbmPlantArgs pl) {
+    srbm_rti_fused_body<K3_RPT_SHORT>(Pp, insts, works, first_index, steps, d_state, d_time, d_ee, pl);
 }
 __global__ __launch_bounds__(K3_THREADS) void srbm_rti_fused_long(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works,
                                                                   int first_index, int steps, double* __restrict__ d_state, double* __restrict__ d_time,
-                                                                  double* __restrict__ d_ee) {
-    srbm_rti_fused_body<K3_RPT>(Pp, insts, works, first_index, steps, d_state, d_time, d_ee);
+                                                                  double* __restrict__ d_ee, const SrbmPlantArgs pl) {
+    srbm_rti_fused_body<K3_RPT>(Pp, insts, works, first_index, steps, d_state, d_time, d_ee, pl);
 }
 
 // EndEffectorSplines::SetContactTimes (end_effector_splines.cpp:860-892) for every foot of every instance
@@ -371,6 +382,7 @@ int srbm_batch_destroy(srbm_batch* h) {
     (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->dp); (void)hipFree(h->insts); (void)hipFree(h->works);
     (void)hipFree(h->d_state); (void)hipFree(h->d_time); (void)hipFree(h->d_ee);
+    (void)hipFree(h->d_plant); (void)hipFree(h->d_push_time); (void)hipFree(h->d_push_impulse);
     if (h->owns_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -450,8 +462,7 @@ int srbm_get_real_time_update_dev(srbm_batch* h, const double* state_dev, const 
     HIPCHK(hipMemcpyAsync(h->d_time, time_dev, sizeof(double) * B, hipMemcpyDeviceToDevice, h->stream));
     return launch_step(h);
 }
-int srbm_rti_advance(srbm_batch* h, int first_index, int steps) {
-    if (!h || steps < 0) return fail("bad arguments");
+static int launch_fused(srbm_batch* h, int first_index, int steps, const SrbmPlantArgs& pl) {
     HIPCHK(hipSetDevice(h->device));
     if (upload_params(h)) return -1;
     if (steps == 0) return 0;
@@ -460,13 +471,61 @@ int srbm_rti_advance(srbm_batch* h, int first_index, int steps) {
     if (tm) HIPCHK(hipEventRecord(h->ev_start[h->ev_used], h->stream));
     if (h->hp.N <= K3_SHORT_N)
         hipLaunchKernelGGL(srbm_rti_fused, dim3(h->batch), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works, first_index, steps,
-                           h->d_state, h->d_time, h->d_ee);
+                           h->d_state, h->d_time, h->d_ee, pl);
     else
         hipLaunchKernelGGL(srbm_rti_fused_long, dim3(h->batch), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works, first_index, steps,
-                           h->d_state, h->d_time, h->d_ee);
+                           h->d_state, h->d_time, h->d_ee, pl);
     if (tm) { HIPCHK(hipEventRecord(h->ev_stop[h->ev_used], h->stream)); h->ev_steps[h->ev_used] = steps; h->ev_used++; }
     HIPCHK(hipGetLastError());
     return 0;
+}
+int srbm_rti_advance(srbm_batch* h, int first_index, int steps) {
+    if (!h || steps < 0) return fail("bad arguments");
+    return launch_fused(h, first_index, steps, SrbmPlantArgs{nullptr, nullptr, nullptr, 1, 0});
+}
+
+// ---- closed-loop rollout harness (srbm_plant.hiph) ----
+static int plant_alloc(srbm_batch* h) {
+    if (h->d_plant) return 0;
+    const size_t B = h->batch;
+    HIPCHK(hipMalloc(&h->d_plant, sizeof(double) * 13 * B));
+    HIPCHK(hipMalloc(&h->d_push_time, sizeof(double) * B));
+    HIPCHK(hipMalloc(&h->d_push_impulse, sizeof(double) * 6 * B));
+    return 0;
+}
+int srbm_plant_set_state(srbm_batch* h, const double* state) {
+    if (!h || !state) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (plant_alloc(h)) return -1;
+    HIPCHK(hipMemcpyAsync(h->d_plant, state, sizeof(double) * 13 * h->batch, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int srbm_plant_get_state(srbm_batch* h, double* state) {
+    if (!h || !state) return fail("bad arguments");
+    if (!h->d_plant) return fail("the plant state has not been set (srbm_plant_set_state)");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(state, h->d_plant, sizeof(double) * 13 * h->batch, hipMemcpyDeviceToHost));
+    return 0;
+}
+int srbm_plant_set_push(srbm_batch* h, const double* time, const double* impulse) {
+    if (!h || (time == nullptr) != (impulse == nullptr)) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (plant_alloc(h)) return -1;
+    h->push_set = time != nullptr;
+    if (time) {
+        HIPCHK(hipMemcpyAsync(h->d_push_time, time, sizeof(double) * h->batch, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_push_impulse, impulse, sizeof(double) * 6 * h->batch, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+int srbm_closed_loop_advance(srbm_batch* h, int first_index, int steps, int substeps, int advance_time) {
+    if (!h || steps < 0 || substeps < 1) return fail("bad arguments");
+    if (!h->d_plant) return fail("the plant state has not been set (srbm_plant_set_state)");
+    return launch_fused(h, first_index, steps, SrbmPlantArgs{h->d_plant, h->push_set ? h->d_push_time : nullptr, h->push_set ? h->d_push_impulse : nullptr,
+                                                              substeps, advance_time ? 1 : 0});
 }
 // the same protocol, one kernel launch per phase and step (grid-wide synchronisation between the phases); kept for
 // A/B measurements against the fused kernel

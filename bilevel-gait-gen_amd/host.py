@@ -203,6 +203,25 @@ class BatchMPC:
     def rti_advance_unfused(self, first_index, steps):
         self._chk(self.L.srbm_rti_advance_unfused(self.h, int(first_index), int(steps)))
 
+    # ---- closed-loop rollout harness (include/srbm_rti.h: srbm_plant_*, srbm_closed_loop_advance) ----
+    def plant_set_state(self, state):
+        self._chk(self.L.srbm_plant_set_state(self.h, _d(self._bcast(state, 13))))
+
+    def plant_state(self):
+        out = np.zeros((self.batch, 13))
+        self._chk(self.L.srbm_plant_get_state(self.h, _d(out)))
+        return out
+
+    def plant_set_push(self, time=None, impulse=None):
+        """one push per instance: lin-mom += impulse[:3], ang-mom += impulse[3:] when the plant passes `time`; None clears"""
+        if time is None:
+            self._chk(self.L.srbm_plant_set_push(self.h, None, None))
+        else:
+            self._chk(self.L.srbm_plant_set_push(self.h, _d(self._bcast(time, 1)), _d(self._bcast(impulse, 6))))
+
+    def closed_loop_advance(self, first_index, steps, substeps=1, advance_time=False):
+        self._chk(self.L.srbm_closed_loop_advance(self.h, int(first_index), int(steps), int(substeps), int(bool(advance_time))))
+
     def synchronize(self):
         self._chk(self.L.srbm_synchronize(self.h))
 

@@ -60,6 +60,24 @@ int srbm_get_real_time_update_dev(srbm_batch* h, const double* state_dev, const 
 int srbm_rti_advance(srbm_batch* h, int first_index, int steps);
 /* same protocol with one kernel launch per phase and step (A/B measurements against the fused kernel) */
 int srbm_rti_advance_unfused(srbm_batch* h, int first_index, int steps);
+
+/* ---- closed-loop rollout harness ----
+ * What the reference closes over MuJoCo (test/simulation_mpc.cpp:186-215), device resident for a batch: the plant is
+ * the single-rigid-body model itself, SingleRigidBodyModel::CalcDynamics (mpc/models/single_rigid_body_model.cpp:
+ * 222-256) integrated by RKIntegrator::CalcIntegral (mpc/rk_integrator.cpp:14-30: explicit Euler on the tangent state)
+ * under the forces and foot locations of the current trajectory, plus one push (momentum impulse) per instance.
+ * Iteration i, t = (first_index+i)*dt (the current trajectory must start at t, e.g. first_index = 0 after
+ * srbm_create_initial_run at time 0):
+ *     x <- CalcIntegral(x, trajectory, t, substeps steps of dt/substeps)     advance_time = 0: every sub-step at time t
+ *                                                                            (as coded), 1: time moves with the sub-steps
+ *     if t < push_time <= t+dt:  lin-mom += impulse[0..2], ang-mom += impulse[3..5]
+ *     MPC::GetRealTimeUpdate(x, t+dt, foot locations of the trajectory at t+dt)
+ * srbm_plant_set_state: x[batch][13] (manifold state, as srbm_create_initial_run); srbm_plant_set_push: time[batch],
+ * impulse[batch][6], both NULL to clear.  srbm_closed_loop_advance is asynchronous like srbm_rti_advance. */
+int srbm_plant_set_state(srbm_batch* h, const double* state);
+int srbm_plant_get_state(srbm_batch* h, double* state);
+int srbm_plant_set_push(srbm_batch* h, const double* time, const double* impulse);
+int srbm_closed_loop_advance(srbm_batch* h, int first_index, int steps, int substeps, int advance_time);
 int srbm_synchronize(srbm_batch* h);
 void* srbm_stream(srbm_batch* h);            /* hipStream_t the kernels are launched on */
 

@@ -79,6 +79,11 @@ public:
     // the loop of test/gait_opt_playground.cpp:113-126, device resident
     void RtiAdvance(int first_index, int steps) { check(srbm_rti_advance(h_, first_index, steps)); }
     void Synchronize() { check(srbm_synchronize(h_)); }
+    // closed-loop rollout harness: plant = CalcDynamics + RKIntegrator::CalcIntegral under the current trajectory (srbm_rti.h)
+    void PlantSetState(const vector_t& state) { need(state, 13 * batch_); check(srbm_plant_set_state(h_, state.data())); }
+    vector_t PlantGetState() const { vector_t s((size_t)batch_ * 13); check(srbm_plant_get_state(h_, s.data())); return s; }
+    void PlantSetPush(const vector_t& time, const vector_t& impulse) { need(time, batch_); need(impulse, 6 * batch_); check(srbm_plant_set_push(h_, time.data(), impulse.data())); }
+    void ClosedLoopAdvance(int first_index, int steps, int substeps, bool advance_time) { check(srbm_closed_loop_advance(h_, first_index, steps, substeps, advance_time ? 1 : 0)); }
     // MPC::UpdateContactTimes (mpc.cpp:1085-1088): times [batch][4][max_contacts]
     void UpdateContactTimes(const vector_t& times, int max_contacts) { need(times, 4 * max_contacts * batch_); check(srbm_update_contact_times(h_, times.data(), max_contacts)); }
     // MPC::AdjustForCurrentContacts (mpc.cpp:1195-1203): time [batch], in_contact [batch][4]

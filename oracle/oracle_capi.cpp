@@ -192,6 +192,18 @@ double orc_mpc_ee_value(void* p, int ee, int is_position, int coord, double t) {
     return h->mpc->GetTrajectory().EE(ee).ValueAt(is_position ? orc::Position : orc::Force, coord, t);
 }
 
+// plant of the closed-loop harness: RKIntegrator::CalcIntegral (rk_integrator.cpp:14-30) under the current trajectory
+int orc_mpc_plant_integrate(void* p, const double* state13, double time, double dt, int num_steps, int advance_time, double* out13) {
+    auto* h = static_cast<OrcMPC*>(p);
+    try {
+        orc::Vec13 ic;
+        for (int i = 0; i < 13; i++) ic[i] = state13[i];
+        const orc::Vec13 r = h->mpc->Model().CalcIntegral(ic, h->mpc->GetTrajectory(), time, dt, num_steps, advance_time);
+        for (int i = 0; i < 13; i++) out13[i] = r[i];
+    } catch (const std::exception& e) { h->err = e.what(); return -1; }
+    return 0;
+}
+
 // ---- bilevel sensitivity step (gait_optimizer.cpp / clarabel_interface.cpp:262-612) ----
 // dHdth out: concatenated per foot (foot-major); returns number of entries, -1 if the last solve was not "Solved"
 int orc_gait_gradient(void* p, double* dHdth) {

@@ -323,6 +323,18 @@ struct SRBModel {
         return xd;
     }
 
+    // RKIntegrator::CalcIntegral, /root/reference/mpc/rk_integrator.cpp:14-30: num_steps explicit Euler steps of size dt on the
+    // tangent state, every one of them evaluated at the SAME time init_time (as coded; the midpoint variant is commented
+    // out there).  advance_time != 0 is the harness's variant with the time moving with the sub-steps.
+    Vec13 CalcIntegral(const Vec13& ic, const Trajectory& traj, double init_time, double dt, int num_steps, int advance_time = 0) const {
+        Vec12 ts = ManifoldToTangent(ic);
+        for (int i = 0; i < num_steps; i++) {
+            const Vec12 f = CalcDynamics(ts.data(), traj, advance_time ? init_time + i * dt : init_time);
+            for (int c = 0; c < 12; c++) ts[c] = ts[c] + dt * f[c];
+        }
+        return TangentToManifold(ts.data());
+    }
+
     // :55-169.  A is 12x12 row-major, B is 12 x num_inputs row-major, C is 12.
     void GetLinearDynamics(const Vec13& state, const Trajectory& traj, double time, std::vector<double>& A,
                            std::vector<double>& B, Vec12& C) const {

@@ -9,7 +9,7 @@ ROUND=${1:-r01}
 OUT=gpurun_out/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="bench.py --no-cpu-baseline --gait-steps 0"
+CMD="bench.py --no-cpu-baseline --gait-steps 0 --closed-loop-steps 0"
 python3 $CMD > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc --output-format csv -- python3 $CMD > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err

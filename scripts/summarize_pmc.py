@@ -49,7 +49,7 @@ write_kb, _ = counter('pmc_write', 'WRITE_SIZE')
 hbm = (2.0 * fetch_kb + write_kb) * 1024.0
 json.dump({
     'kernel': KERNEL, 'steps_per_launch': steps, 'launches_seen': nl,
-    'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two separate passes, no other tracing) -- python3 bench.py --no-cpu-baseline --gait-steps 0',
+    'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two separate passes, no other tracing) -- python3 bench.py --no-cpu-baseline --gait-steps 0 --closed-loop-steps 0',
     'FETCH_SIZE_KB_per_launch': fetch_kb, 'WRITE_SIZE_KB_per_launch': write_kb,
     'correction': 'gfx950: FETCH_SIZE counts 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM section; calibrated there for '
                   '16 B/lane streaming reads, this kernel reads 8 B/lane: upper bound); WRITE_SIZE as reported',

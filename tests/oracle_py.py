@@ -199,6 +199,13 @@ class OracleMPC:
     def ee_value(self, ee, is_position, coord, t):
         return self.L.orc_mpc_ee_value(self.h, ee, int(is_position), coord, C.c_double(t))
 
+    def plant_integrate(self, state13, t, dt, num_steps, advance_time=0):
+        """RKIntegrator::CalcIntegral (rk_integrator.cpp:14-30) under the current trajectory"""
+        out = np.zeros(13)
+        self._chk(self.L.orc_mpc_plant_integrate(self.h, _d(np.ascontiguousarray(state13, float)), C.c_double(t), C.c_double(dt),
+                                                 int(num_steps), int(advance_time), _d(out)))
+        return out
+
     # ---- bilevel step ----
     def gait_gradient(self):
         g = np.zeros(128)

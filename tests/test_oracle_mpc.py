@@ -150,3 +150,27 @@ def test_config_b_fixture_is_reproducible_from_the_oracle():
         for a, r in zip(got['steps'], ref['steps']):
             assert (a['status'], a['iters'], a['n'], a['m'], a['alpha']) == (r['status'], r['iters'], r['n'], r['m'], r['alpha'])
             assert abs(a['x_sum'] - r['x_sum']) <= 1e-9 * max(1.0, abs(r['x_sum']))
+
+
+def test_plant_integral_restates_the_euler_integrator():
+    """RKIntegrator::CalcIntegral (rk_integrator.cpp:14-30) over CalcDynamics (single_rigid_body_model.cpp:222-256): n
+    sub-steps at the fixed time are n single steps; the position rate is momentum / mass; the linear-momentum rate is
+    m g + sum of the foot forces of the trajectory (no stored vector exists in the reference for this function)."""
+    cfg = load_config(num_nodes=10)
+    s0 = np.array(cfg['srb_init'], float)
+    ee = np.array([[0.2, 0.2, 0], [0.2, -0.2, 0], [-0.2, 0.2, 0], [-0.2, -0.2, 0]], float)
+    o = OracleMPC(cfg); o.set_warmstart(s0); o.initial_run(s0, ee)
+    x = s0.copy(); x[3:6] = [1.0, -2.0, 0.5]
+    t, h = 0.02, 0.004
+    a = o.plant_integrate(x, t, h, 3, 0)
+    b = x.copy()
+    for _ in range(3): b = o.plant_integrate(b, t, h, 1, 0)
+    assert np.abs(a - b).max() < 1e-14
+    one = o.plant_integrate(x, t, h, 1, 0)
+    mass = cfg['mass']
+    assert np.allclose(one[0:3], x[0:3] + h * x[3:6] / mass, atol=1e-15)
+    F = np.array([[o.ee_value(e, 0, c, t) for c in range(3)] for e in range(4)]).sum(axis=0)
+    assert np.allclose(one[3:6], x[3:6] + h * (np.array([0, 0, -9.81 * mass]) + F), atol=1e-12)
+    # time moving with the sub-steps differs from the frozen-time integral as soon as the forces vary
+    c = o.plant_integrate(x, t, h, 3, 1)
+    assert np.abs(c - a).max() > 0
