@@ -126,24 +126,29 @@ __global__ void srbm_k_next_inputs(const SrbmParams* __restrict__ Pp, const Srbm
 // working sets of kernels 1, 2 and 4 are windows of the IPM kernel's dynamic LDS.
 // Each phase is an out-of-line function: its registers are allocated for that phase alone (inlined into one body, values of
 // one phase were kept live -- spilled -- across the others and out of the step loop).
-static __device__ __noinline__ void srbm_phase_inputs_assemble(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works,
-                                                        double time, double* __restrict__ d_state, double* __restrict__ d_time, double* __restrict__ d_ee,
-                                                        double* __restrict__ plant, const double* __restrict__ push_time,
-                                                        const double* __restrict__ push_impulse, int substeps, int advance_time) {
-    if (plant) srbm_plant_inputs_body(Pp, insts, time, substeps, advance_time, plant, push_time, push_impulse, d_state, d_time, d_ee);
-    else srbm_next_inputs_body(Pp, insts, time, d_state, d_time, d_ee);
-    __syncthreads();
-    srbm_k1_assemble_body(Pp, insts, works, d_state, d_time, d_ee, *reinterpret_cast<K1Shared*>(k3_smem));
-}
-static __device__ __noinline__ void srbm_phase_condense(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works) {
-    srbm_k2_condense_body(Pp, insts, works, *reinterpret_cast<K2Shared*>(k3_smem));
+// Everything between two solves is ONE out-of-line function -- update of step s (when `update`), then inputs, assembly and
+// condensing of step s+1 (when `next`): an out-of-line function saves the callee-saved registers it uses on entry (448 B
+// per lane here, it uses all of them), so fewer, larger phases mean less scratch traffic per step.
+static __device__ __noinline__ void srbm_phase_between_solves(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works,
+                                                              int update, int next, double time, double* __restrict__ d_state, double* __restrict__ d_time,
+                                                              double* __restrict__ d_ee, double* __restrict__ plant, const double* __restrict__ push_time,
+                                                              const double* __restrict__ push_impulse, int substeps, int advance_time) {
+    if (update) {
+        srbm_k4_update_body(Pp, insts, works, *reinterpret_cast<K4Shared*>(k3_smem));
+        __syncthreads();
+    }
+    if (next) {
+        if (plant) srbm_plant_inputs_body(Pp, insts, time, substeps, advance_time, plant, push_time, push_impulse, d_state, d_time, d_ee);
+        else srbm_next_inputs_body(Pp, insts, time, d_state, d_time, d_ee);
+        __syncthreads();
+        srbm_k1_assemble_body(Pp, insts, works, d_state, d_time, d_ee, *reinterpret_cast<K1Shared*>(k3_smem));
+        __syncthreads();
+        srbm_k2_condense_body(Pp, insts, works, *reinterpret_cast<K2Shared*>(k3_smem));
+    }
 }
 template <int RPT>
 static __device__ __noinline__ void srbm_phase_ipm(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works) {
     srbm_k3_body<0, RPT>(Pp, insts, works);
-}
-static __device__ __noinline__ void srbm_phase_update(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works) {
-    srbm_k4_update_body(Pp, insts, works, *reinterpret_cast<K4Shared*>(k3_smem));
 }
 // closed-loop mode of the fused kernel: plant != nullptr (srbm_plant.hiph)
 struct SrbmPlantArgs {
@@ -155,15 +160,14 @@ __device__ __forceinline__ void srbm_rti_fused_body(const SrbmParams* __restrict
                                                     int first_index, int steps, double* __restrict__ d_state, double* __restrict__ d_time,
                                                     double* __restrict__ d_ee, const SrbmPlantArgs pl) {
     static_assert(K1_THREADS == K3_THREADS && K2_THREADS == K3_THREADS && K4_THREADS == K3_THREADS, "the fused kernel runs all phases with one block size");
-    for (int s = 0; s < steps; s++) {
+    for (int s = 0; s <= steps; s++) {
+        // between-solves phase: update of step s-1, inputs / assembly / condensing of step s
         const double time = (first_index + s) * Pp->dt;
-        srbm_phase_inputs_assemble(Pp, insts, works, time, d_state, d_time, d_ee, pl.plant, pl.push_time, pl.push_impulse, pl.substeps, pl.advance_time);
+        srbm_phase_between_solves(Pp, insts, works, s > 0, s < steps, time, d_state, d_time, d_ee, pl.plant, pl.push_time, pl.push_impulse, pl.substeps,
+                                  pl.advance_time);
         __syncthreads();
-        srbm_phase_condense(Pp, insts, works);
-        __syncthreads();
+        if (s == steps) break;
         srbm_phase_ipm<RPT>(Pp, insts, works);
-        __syncthreads();
-        srbm_phase_update(Pp, insts, works);
         __syncthreads();
     }
 }
