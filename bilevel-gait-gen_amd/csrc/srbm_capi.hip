@@ -194,6 +194,8 @@ __global__ void srbm_k_set_contact_times(const SrbmParams* __restrict__ Pp, Srbm
 // ---------------- host helpers ----------------
 static int upload_params(srbm_batch* h) {
     if (!h->params_dirty) return 0;
+    h->hp.q_diag = 1;
+    for (int i = 0; i < 144; i++) if (i % 13 != 0 && (h->hp.Q[i] != 0.0 || h->hp.Phi[i] != 0.0)) h->hp.q_diag = 0;
     HIPCHK(hipMemcpyAsync(h->dp, &h->hp, sizeof(SrbmParams), hipMemcpyHostToDevice, h->stream));
     h->params_dirty = false;
     return 0;

@@ -35,6 +35,7 @@ enum { SRBM_ERR_TIME_SMALL = 1, SRBM_ERR_TIME_LARGE = 2, SRBM_ERR_INVALID_TIME =
 typedef struct SrbmParams {
     int batch, N;
     int max_iter, lds_doubles;      /* IPM iteration limit; doubles of dynamic LDS the IPM kernel is launched with */
+    int q_diag, pad0;               /* Q and Phi are diagonal (every configuration of the reference): the condensing kernel then skips the 12x12 products */
     double dt, mu_fric, force_bound, swing_height, foot_offset, force_cost;
     double box0[2];                 /* configured ee_box_size (ee_bounds_, msrb.cpp:22) */
     double mass, Ir[9], Ir_inv[9];
