@@ -15,3 +15,8 @@ names = ['staging/F,R/Bu', 'rollout', 'costates', 'assemble+row duals', 'candida
 tot = out[32:41].sum()
 for n, v in zip(names, out[32:41]): print('%-22s %10.0f cycles/step %5.1f%%' % (n, v / 30, 100 * v / tot))
 print('total per step %.0f cycles = %.1f us' % (tot / 30, tot / 30 / 2400))
+names1 = ['staging', 'horizon shift', 'bookkeeping', 'lin. point + column map', 'node records + samples', 'equality rows', 'node blocks + affine']
+tot1 = out[44:51].sum()
+print('kernel 1:')
+for n, v in zip(names1, out[44:51]): print('%-24s %10.0f cycles/step %5.1f%%' % (n, v / 30, 100 * v / tot1))
+print('total per step %.0f cycles = %.1f us' % (tot1 / 30, tot1 / 30 / 2400))
