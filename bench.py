@@ -2,33 +2,41 @@
 """Headline benchmark: MPC RTI iterations / second, batched A1 SRBM, N=20 (BASELINE.json `metric`, config[1]).
 
 Workload (Config B): 256 independent MPC instances PER GPU, horizon N=20, dt=0.05,
-apps/a1_configuration.yaml values, synthetic initial states (std::mt19937_64-style seeds 20240112+b, here numpy MT19937).
-Protocol: 10 cold-start solves per instance (MPC::CreateInitialRun, untimed set-up), W warm-up RTI steps, then K timed
-RTI steps with t_i = i*dt and state := node 1 of the previous trajectory (test/gait_opt_playground.cpp:113-126), run
-device-resident (inputs are in HBM when the timed region starts).  One "step" = one RTI iteration of every instance
-of the batch (shift -> assemble -> condense -> QP solve -> line search -> trajectory update).
+apps/a1_configuration.yaml values, synthetic initial states (seeds 20240112+b, numpy MT19937).
+Protocol: 10 cold-start solves per instance (MPC::CreateInitialRun, untimed set-up), W warm-up RTI steps, then the timed
+region: K RTI steps with t_i = i*dt and state := node 1 of the previous trajectory (test/gait_opt_playground.cpp:113-126),
+device-resident (inputs are in HBM when the region starts), closed by the all-gather of the result records.  The region is
+repeated `--repeats` times back to back (the protocol simply continues) and the MEDIAN region is reported, so that a
+20-step and a 100-step run agree (the first region after start-up runs at ramping clocks).  One "step" = one RTI iteration
+of every instance of the batch (shift -> assemble -> condense -> QP solve -> line search -> trajectory update).
 
-Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); instances are sharded over ranks (weak
-scaling: 256 per GPU) with no data-path collective; one all-gather of the per-instance result records closes the timed
-region.  Rank 0 prints ONE JSON line.
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); instances are sharded over ranks (weak scaling: 256
+per GPU) with no data-path collective; one all-gather of the per-instance result records (primal, dual, contact times)
+closes every timed region.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment spawns the N ranks
+itself (fresh child processes, the parent never touches a GPU); under torchrun the ranks are already there.  Rank 0 prints
+ONE JSON line.  `--dry-run` walks the same launcher / sharding / gather path on CPU (gloo) without any HIP call.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (public spec; the CDNA guide lists no fp64 row)
+MFMA_FLOP = 2048.0           # one v_mfma_f64_16x16x4_f64: 16 x 16 x 4 multiply-adds
 BATCH_PER_GPU = 256
-RESULT_LD = 8 + 21 * 12 + 160
+PROFILE_ROUND = 'r02'
 
 
-# ---------- helpers shared with the CPU (gloo) test of the sharding logic ----------
+# ---------- helpers shared with the CPU (gloo) tests of the sharding logic ----------
 def shard_range(total, rank, world):
     """contiguous block [lo, hi) of `total` instances owned by `rank`"""
     per = total // world
@@ -79,6 +87,14 @@ def config_b_instance(cfg, b):
     return state, ee
 
 
+def config_c_instance(cfg, b):
+    """instance b of Config C: Config B's perturbations around the srb_init of apps/a1_gait_opt_config.yaml
+    (height 0.34); the target of that file is x_des = y_des = 1"""
+    state, ee = config_b_instance(cfg, b)
+    state[2] += cfg['srb_init'][2] - 0.30
+    return state, ee
+
+
 def config_d_instance(cfg, b):
     """instance b of Config D: apps/a1_config_distr_rejection.yaml values (N=50, dt=0.02); the file's
     single push becomes a distribution -- lin-mom xy ~ N(0, 2.5^2) truncated at 3 sigma, yaw ang-mom ~ N(0, 0.2^2), seed 777 + b"""
@@ -95,74 +111,121 @@ def config_d_instance(cfg, b):
     return state, ee
 
 
-def _cpu_rti_run(cfg, inst, steps=30):
-    """one Config-B instance on the oracle: 10 cold-start solves (untimed), then `steps` timed RTI steps; returns seconds"""
-    from oracle_py import OracleMPC
-    dt = cfg['integrator_dt']
-    s0, ee = config_b_instance(cfg, inst)
-    o = OracleMPC(cfg)
-    o.set_warmstart(s0)
-    o.initial_run(s0, ee)
-    state = s0
-    t0 = time.perf_counter()
-    for i in range(steps):
-        t = i * dt
-        eel = np.array([[o.ee_value(e, 1, c, t) for c in range(3)] for e in range(4)])
-        o.rti(state, t, eel)
-        state = o.states()[1]
-    return time.perf_counter() - t0
+# ---------- CPU baseline: the oracle's C++ driver, built and run on THIS box ----------
+def write_cpu_baseline_input(cfg, n_inst, path):
+    v = [cfg['num_nodes'], cfg['integrator_dt'], cfg['friction_coef'], cfg['force_bound'], cfg['swing_height'], cfg['foot_offset'],
+         cfg['ee_box_size'][0], cfg['ee_box_size'][1], cfg['force_cost'], cfg['mass']]
+    v += list(np.asarray(cfg['Ir'], float).reshape(-1)) + list(np.asarray(cfg['hip_xy'], float).reshape(-1))
+    v += [float(x) for x in cfg['Q_srbd_diag']] + [float(x) for x in cfg['srb_target']]
+    v.append(n_inst)
+    for b in range(n_inst):
+        s, ee = config_b_instance(cfg, b)
+        v += list(s) + list(ee.reshape(-1))
+    np.asarray(v, dtype=np.float64).tofile(path)
 
 
-def cpu_baseline(cfg, seconds_budget=15.0):
-    """The oracle (CPU restatement of the reference algorithm, oracle/) timed on this box's host cores: a bounded sample
-    of the SAME workload -- instances 0.. of Config B, 10 cold-start solves each (untimed) then 30 timed RTI steps --
-    single thread (`value`, `cores` = 1) and, as SURVEY.md 8(d) asks, over instances on all host cores of the box
-    (`all_cores`: one oracle object per thread; the C++ solves release the GIL).  Reported beside the GPU number; it is
-    not the target."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle_py import build_oracle
-    build_oracle()
-    done, el, inst = 0, 0.0, 0
-    while el < seconds_budget and inst < 64:
-        el += _cpu_rti_run(cfg, inst)
-        done += 30
-        inst += 1
-    out = {'value': done / el, 'unit': 'it/s', 'cores': 1, 'kind': 'port',
-           'sample': '%d Config-B instances x 30 RTI steps after 10 cold-start solves each, oracle/ (C++ -O2, 1 thread)' % inst}
+def host_cpu_share():
+    """host threads this process may actually use: the affinity mask, capped by the cgroup CPU quota (a one-GPU box shows the
+    256 hardware threads of its host but is entitled to 16 of them)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     try:
-        ncore = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))     # 16 = the CPU share of a one-GPU box
-        per_thread = 2
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
 
-        def worker(k):
-            return sum(_cpu_rti_run(cfg, 64 + k * per_thread + j) for j in range(per_thread))
-        t0 = time.perf_counter()
-        with ThreadPoolExecutor(ncore) as ex:
-            times = list(ex.map(worker, range(ncore)))
-        wall = time.perf_counter() - t0
-        out['all_cores'] = {'value': 30 * per_thread * ncore / max(times), 'cores': ncore, 'wall_s_incl_cold_starts': wall,
-                            'sample': '%d threads x %d instances x 30 RTI steps (timed part of the slowest thread)' % (ncore, per_thread)}
-    except Exception as e:        # the single-thread figure stands on its own
-        out['all_cores'] = {'error': str(e)}
-    return out
+
+def cpu_baseline(cfg, n_single=48, per_thread=4, steps=30):
+    """The oracle (CPU restatement of the reference algorithm, oracle/) timed on this box's host cores, as BASELINE.md
+    section 3.4 planned: oracle/cpu_baseline.cpp compiled HERE with -O3 -march=native -ffp-contract=off + OpenMP, a bounded
+    sample of the SAME workload -- Config-B instances, 10 cold-start solves each (untimed) then 30 timed RTI steps --
+    (i) on one thread (`value`, `cores` = 1) and (ii) OpenMP over instances on all host threads (`all_cores`).  Reported
+    beside the GPU number; it is not the target."""
+    import tempfile
+    odir = os.path.join(ROOT, 'oracle')
+    subprocess.check_call(['make', '-s', '-C', odir, 'cpu_baseline'])
+    ncpu = host_cpu_share()
+    with tempfile.TemporaryDirectory() as td:
+        inp = os.path.join(td, 'in.bin')
+        write_cpu_baseline_input(cfg, 256, inp)
+        env = dict(os.environ, OMP_NUM_THREADS=str(ncpu), OMP_PROC_BIND='close')
+        r = subprocess.run([os.path.join(odir, '_native', 'cpu_baseline'), inp, str(n_single), str(per_thread), str(steps)],
+                           capture_output=True, text=True, env=env, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError('cpu_baseline failed: ' + r.stderr[-500:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    cpu_model = ''
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                cpu_model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    s, a = d['single'], d['all_cores']
+    return {'value': s['it_per_s'], 'unit': 'it/s', 'cores': 1, 'kind': 'port',
+            'sample': '%d Config-B instances x %d RTI steps after 10 cold-start solves each; oracle/cpu_baseline.cpp, g++ -O3 -march=native '
+                      '-ffp-contract=off, 1 thread, %.1f s, mean %.1f IPM iterations per solve' % (s['instances'], s['steps'], s['seconds'], s['mean_ipm_iterations']),
+            'all_cores': {'value': a['it_per_s'], 'cores': a['threads'], 'wall_s_incl_cold_starts': a['wall_s_incl_cold_starts'],
+                          'sample': 'OpenMP, %d threads x %d instances x %d RTI steps (timed part of the slowest thread)' % (a['threads'], per_thread, a['steps'])},
+            'cpu_model': cpu_model, 'nproc': ncpu, 'not_solved': s['not_solved'] + a['not_solved']}
+
+
+# ---------- HBM traffic of the dominant kernel from the committed PMC summary ----------
+def kernel_source_sha():
+    """sha256 over the kernel sources + C-ABI header: a PMC summary is only quoted for the code it was measured on"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'bilevel-gait-gen_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.hiph', '.h')):
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(steps):
-    """HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE need two separate rocprofv3
-    runs, so the figure is read from the committed summary of those runs, profiles/r01/k3_pmc_traffic.json, and scaled to the
-    number of RTI steps of this launch; None if absent)"""
-    path = os.path.join(ROOT, 'profiles', 'r01', 'k3_pmc_traffic.json')
+    """HBM bytes per launch of the dominant kernel from the two PMC passes (FETCH_SIZE / WRITE_SIZE need separate rocprofv3 runs,
+    scripts/collect_profiles.sh), read from the committed summary profiles/<round>/pmc_summary.json and scaled to the RTI steps
+    of one launch.  None unless the summary was taken on exactly these kernel sources."""
+    path = os.path.join(ROOT, 'profiles', PROFILE_ROUND, 'pmc_summary.json')
     try:
         d = json.load(open(path))
-        return float(d['hbm_bytes_per_launch']) * steps / float(d['steps_per_launch'])
+        if d.get('kernel_source_sha') != kernel_source_sha():
+            return None, None
+        return float(d['hbm_bytes_per_step']) * steps, d
     except Exception:
-        return None
+        return None, None
+
+
+# ---------- rank launcher ----------
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` (N > 1) outside torchrun: start N fresh rank processes of this same script.  The parent has not
+    imported torch and never touches a GPU; nothing is exec'd from a GPU-initialised process."""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps run back to back; the median is reported')
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='instances per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', choices=['B', 'D'], default='B',
@@ -170,84 +233,143 @@ def main():
     ap.add_argument('--closed-loop-steps', type=int, default=20,
                     help='extra, separately timed segment: closed-loop rollouts against the SRBM plant with pushes (0 = skip)')
     ap.add_argument('--gait-steps', type=int, default=30,
-                    help='extra, separately timed segment: controller loop with the bilevel (gait) step every 5th iteration (0 = skip)')
+                    help='extra, separately timed segment (Config C): controller loop with the bilevel (gait) step every 5th iteration (0 = skip)')
+    ap.add_argument('--dry-run', action='store_true', help='CPU rehearsal of the launcher / sharding / gather path (gloo, no HIP call)')
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.repeats < 1:
+        raise SystemExit('bench.py: --gpus, --steps and --repeats must be positive')
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a wrong n_gpus\n' % (args.gpus, world))
+        sys.exit(3)
 
     import torch
     import torch.distributed as dist
     from srbm_loader import host
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
-
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     cfg = host.load_config('a1_configuration' if args.workload == 'B' else 'a1_config_distr_rejection')
     B = args.batch if args.workload == 'B' else (512 if args.batch == BATCH_PER_GPU else args.batch)
     make_instance = config_b_instance if args.workload == 'B' else config_d_instance
     lo, hi = shard_range(B * world, rank, world)            # this rank's instances of the global batch
+    n_inst = B * world
+
+    if args.dry_run:
+        # same sharding and the same collective on CPU tensors; the records carry the global instance index instead of a solution
+        if world > 1:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        ld = 16
+        rec = torch.zeros((hi - lo, ld), dtype=torch.float64)
+        rec[:, 0] = 0.0
+        rec[:, 1] = torch.arange(lo, hi, dtype=torch.float64)
+        allrec = gather_records(rec, world)
+        ok = bool(torch.equal(allrec[:, 1], torch.arange(n_inst, dtype=torch.float64)))
+        el = max_over_ranks(1.0)
+        if rank == 0:
+            print(json.dumps({'metric': 'MPC RTI iterations/sec (batched A1 SRBM, N=%d)' % cfg['num_nodes'], 'value': 0.0, 'unit': 'it/s',
+                              'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'dry_run': True, 'scaling': 'weak',
+                              'config': {'batch_per_gpu': B, 'global_batch': n_inst, 'records_gathered': int(allrec.shape[0]), 'gather_ok': ok}}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(0 if ok and el == 1.0 else 4)
+
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
     states, ees = zip(*[make_instance(cfg, b) for b in range(lo, hi)])
     states, ees = np.array(states), np.array(ees).reshape(hi - lo, 12)
 
     mpc = host.BatchMPC(cfg, hi - lo, device=local_rank)
     mpc.set_state_trajectory_warm_start(states)
-    mpc.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+    mpc.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
     mpc.create_initial_run(states, ees)                       # 10 cold-start solves (set-up, untimed)
     mpc.rti_advance(0, args.warmup)
     mpc.synchronize()
-    rec = torch.zeros((hi - lo, RESULT_LD), dtype=torch.float64, device='cuda')
+    LD = mpc.result_record_doubles()                          # status..., primal, dual, contact times (SURVEY.md 8e record)
+    rec = torch.zeros((hi - lo, LD), dtype=torch.float64, device='cuda')
+    if world > 1:                                             # first collective outside the timed region (communicator set-up)
+        gather_records(rec, world)
+        torch.cuda.synchronize()
 
+    mpc.clear_status_accumulators()
     it0, fl0 = mpc.work_counters()
-    mpc.enable_kernel_timing(4)          # the K timed steps are ONE launch of the fused RTI kernel
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    mpc.rti_advance(args.warmup, args.steps)                  # K device-resident RTI steps
-    mpc.pack_results_dev(rec.data_ptr(), RESULT_LD)
-    mpc.synchronize()
-    allrec = gather_records(rec, world)                        # RCCL all-gather of the solved trajectories
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    mf0 = mpc.executed_mfma()
+    mpc.enable_kernel_timing(args.repeats + 2)     # every timed region is ONE launch of the fused RTI kernel
+    region_s = []
+    first = args.warmup
+    allrec = None
+    for rep in range(args.repeats):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mpc.rti_advance(first, args.steps)                    # K device-resident RTI steps
+        mpc.pack_results_dev(rec.data_ptr(), LD)
+        mpc.synchronize()
+        allrec = gather_records(rec, world)                   # RCCL all-gather of the solved trajectories (primal + dual + schedule)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        region_s.append(max_over_ranks(time.perf_counter() - t0))
+        first += args.steps
+    elapsed = float(np.median(region_s))
 
     k3_ms, k3_launches = mpc.kernel_timing()
     it1, fl1 = mpc.work_counters()
-    st, err = mpc.status()
+    mf1 = mpc.executed_mfma()
+    acc_main = mpc.status_accumulated()
 
-    # ---- second segment (Config C): the same batch continues with the gait step every 5th iteration ----
+    # ---- second segment (Config C): N=20 / dt=0.05 with the values of apps/a1_gait_opt_config.yaml, gait step every 5th iteration ----
     gait_stats = None
-    if args.gait_steps > 0:
+    if args.gait_steps > 0 and args.workload == 'B':
         FREQ = 5
-        gait = host.BatchGaitOptimizer(mpc)
-        first = args.warmup + args.steps
-        first += (-first) % FREQ + 1                 # start right after a multiple of FREQ: every block of 5 = 3 RTI + (RTI + GaitOpt) + LineSearch
-        n_ls = sum(1 for r in range(first, first + args.gait_steps) if r % FREQ == 0)
-        n_go = sum(1 for r in range(first, first + args.gait_steps) if (r + 1) % FREQ == 0)
+        cfg_c = host.load_config('a1_gait_opt_config', num_nodes=20, integrator_dt=0.05)
+        sc, ec = zip(*[config_c_instance(cfg_c, b) for b in range(lo, hi)])
+        sc, ec = np.array(sc), np.array(ec).reshape(hi - lo, 12)
+        gm = host.BatchMPC(cfg_c, hi - lo, device=local_rank)
+        gm.set_state_trajectory_warm_start(sc)
+        gm.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
+        gm.create_initial_run(sc, ec)
+        gait = host.BatchGaitOptimizer(gm)
+        gait.rti_advance(0, 6, FREQ)                 # run_num 0..5: includes one gradient + LP (run 4) and one line search (run 5)
+        gm.synchronize()
+        gm.clear_status_accumulators()
+        firstg = 6
+        n_ls = sum(1 for r in range(firstg, firstg + args.gait_steps) if r % FREQ == 0)
+        n_go = sum(1 for r in range(firstg, firstg + args.gait_steps) if (r + 1) % FREQ == 0)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         tg = time.perf_counter()
-        gait.rti_advance(first, args.gait_steps, FREQ)
-        mpc.synchronize()
+        gait.rti_advance(firstg, args.gait_steps, FREQ)
+        gm.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         el_g = max_over_ranks(time.perf_counter() - tg)
-        stg, errg = mpc.status()
-        n_all = B * world
-        solves = n_all * ((args.gait_steps - n_ls) + 10 * n_ls)      # a line search is 10 RTI solves per instance
-        gait_stats = {'workload': 'Config C protocol on the same batch: gait step every 5th iteration (gradient + LP, then 10-candidate line search)',
+        stg, _ = gm.status()
+        accg = gm.status_accumulated()
+        lp_st, _ = gait.lp_result()
+        solves = n_inst * ((args.gait_steps - n_ls) + 10 * n_ls)      # a line search is 10 RTI solves per instance
+        gait_stats = {'workload': 'Config C: %d instances per GPU, N=20, dt=0.05, a1_gait_opt_config.yaml values (mu 0.6, force bound 200, target x=y=1); '
+                                  'controller protocol with the gait step every 5th iteration (gradient + LP, then 10-candidate line search)' % B,
                       'steps': args.gait_steps, 'gait_opt_steps': n_go, 'line_search_steps': n_ls,
-                      'rti_solves_per_s_incl_line_search': solves / el_g, 'gait_steps_per_s': n_all * n_ls / el_g,
+                      'rti_solves_per_s_incl_line_search': solves / el_g, 'gait_steps_per_s': n_inst * n_ls / el_g,
                       'ms_per_step': 1e3 * el_g / args.gait_steps,
-                      'statuses_after': {int(k): int(v) for k, v in zip(*np.unique(stg, return_counts=True))}, 'err_bits': int(np.bitwise_or.reduce(errg))}
+                      'statuses_after': {int(k): int(v) for k, v in zip(*np.unique(stg, return_counts=True))},
+                      'err_bits_all_steps': int(np.bitwise_or.reduce(accg[:, 0])), 'not_solved_all_steps': int(accg[:, 2].sum()),
+                      'lp_status_last': {int(k): int(v) for k, v in zip(*np.unique(lp_st, return_counts=True))}}
+        del gait, gm
     # ---- third segment: closed-loop rollouts, plant = SRBM dynamics under the current trajectory + one push per instance ----
     cl_stats = None
     if args.closed_loop_steps > 0:
@@ -263,6 +385,7 @@ def main():
         cl.plant_set_push(np.full(hi - lo, 2.5 * cfg['integrator_dt']), imp)
         cl.closed_loop_advance(0, 2, SUB, True)
         cl.synchronize()
+        cl.clear_status_accumulators()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -273,45 +396,77 @@ def main():
         if world > 1:
             dist.barrier()
         el_c = max_over_ranks(time.perf_counter() - tc)
-        stc, errc = cl.status()
+        stc, _ = cl.status()
+        accc = cl.status_accumulated()
         cl_stats = {'workload': 'closed loop on a fresh copy of the batch: plant = SRBM dynamics (explicit Euler, %d sub-steps per step) under the current '
                                 'trajectory, one push per instance at t = 2.5 dt (Config D distribution)' % SUB,
-                    'steps': args.closed_loop_steps, 'rti_iterations_per_s': B * world * args.closed_loop_steps / el_c,
+                    'steps': args.closed_loop_steps, 'rti_iterations_per_s': n_inst * args.closed_loop_steps / el_c,
                     'ms_per_step': 1e3 * el_c / args.closed_loop_steps,
-                    'statuses_after': {int(k): int(v) for k, v in zip(*np.unique(stc, return_counts=True))}, 'err_bits': int(np.bitwise_or.reduce(errc)),
+                    'statuses_after': {int(k): int(v) for k, v in zip(*np.unique(stc, return_counts=True))},
+                    'err_bits_all_steps': int(np.bitwise_or.reduce(accc[:, 0])), 'not_solved_all_steps': int(accc[:, 2].sum()),
                     'plant_finite': bool(np.all(np.isfinite(cl.plant_state())))}
         del cl
-    ok = bool(np.all(err == 0) and np.all((st == 0) | (st == 1) | (st == 2)))
-    n_inst = B * world
     value = n_inst * args.steps / elapsed
+
+    # quality of ALL timed solves of this rank (sticky accumulators), reduced over the ranks
+    q = np.array([float(np.bitwise_or.reduce(acc_main[:, 0])), float(acc_main[:, 1].sum()), float(acc_main[:, 2].sum()), float(acc_main[:, 3].sum())])
+    if world > 1:
+        tq = torch.tensor(q, dtype=torch.float64, device='cuda')
+        gl = [torch.zeros_like(tq) for _ in range(world)]
+        dist.all_gather(gl, tq)
+        allq = torch.stack(gl).cpu().numpy()
+        q = np.array([float(np.bitwise_or.reduce(allq[:, 0].astype(np.int64))), allq[:, 1].sum(), allq[:, 2].sum(), allq[:, 3].sum()])
 
     if rank == 0:
         status_all = allrec[:, 0].cpu().numpy()
+        err_all = allrec[:, 5].cpu().numpy().astype(np.int64)
+        if allrec.shape[0] != n_inst:
+            raise SystemExit('gathered %d records for %d instances' % (allrec.shape[0], n_inst))
         k3_avg_s = (k3_ms / max(1, k3_launches)) * 1e-3
         flops_per_launch = (fl1 - fl0) / max(1, k3_launches)
+        mfma_per_launch = (mf1 - mf0) / max(1, k3_launches)
         achieved = flops_per_launch / k3_avg_s / 1e12 if k3_avg_s > 0 else 0.0
+        exec_tflops = mfma_per_launch * MFMA_FLOP / k3_avg_s / 1e12 if k3_avg_s > 0 else 0.0
+        traffic, pmc = pmc_traffic(args.steps) if args.workload == 'B' else (None, None)
+        roof = {'bound': 'mfma', 'limiter': 'latency of dependent chains (1 workgroup of 8 waves per CU, no HBM or matrix-pipe saturation)',
+                'kernel': 'srbm_rti_fused' if cfg['num_nodes'] <= 22 else 'srbm_rti_fused_long',
+                'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_PEAK_TFLOPS,
+                'achieved_is': 'ALGORITHMIC flops (SURVEY.md 8d formula at the sizes and IPM iteration counts executed) / measured launch time',
+                'traffic': traffic, 'avg_launch_ms': k3_avg_s * 1e3, 'launches_timed': k3_launches,
+                'algorithmic_flops_per_launch': flops_per_launch,
+                'executed_mfma_tflops': exec_tflops, 'executed_mfma_frac_of_peak': exec_tflops / FP64_PEAK_TFLOPS,
+                'executed_mfma_instructions_per_launch': mfma_per_launch}
+        if pmc is not None:
+            roof['traffic_source'] = 'profiles/%s/pmc_summary.json (kernel sources %s)' % (PROFILE_ROUND, pmc['kernel_source_sha'])
+            for k in ('mfma_busy_frac', 'lds_bank_conflict_frac', 'valu_busy_frac', 'occupancy_waves_per_cu'):
+                if k in pmc:
+                    roof['pmc_' + k] = pmc[k]
         out = {
             'metric': 'MPC RTI iterations/sec (batched A1 SRBM, N=%d)' % cfg['num_nodes'],
             'value': value, 'unit': 'it/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
+            'dtype': 'f64', 'data': 'synthetic', 'repeats': args.repeats, 'region_ms': [1e3 * v for v in region_s],
             'config': {'workload': ('Config B: %d A1 SRBM MPC instances per GPU, N=20, dt=0.05, a1_configuration.yaml values, '
                                     '10 cold-start solves then open-loop RTI steps (state := node 1)' % B) if args.workload == 'B' else
                                    ('Config D: %d A1 SRBM MPC instances per GPU, N=50, dt=0.02, a1_config_distr_rejection.yaml values, push '
                                     'distribution on the initial momentum, 10 cold-start solves then open-loop RTI steps' % B),
                        'batch_per_gpu': B, 'global_batch': n_inst, 'num_nodes': cfg['num_nodes'], 'parallelism': 'instances sharded x%d' % world,
-                       'all_solved': ok, 'statuses': {int(k): int(v) for k, v in zip(*np.unique(status_all, return_counts=True))},
-                       'mean_ipm_iterations': (it1 - it0) / max(1, (hi - lo) * args.steps)},
-            'roofline': {'bound': 'mfma', 'kernel': 'srbm_rti_fused' if cfg['num_nodes'] <= 22 else 'srbm_rti_fused_long', 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': pmc_traffic(args.steps) if args.workload == 'B' else None,
-                         'avg_launch_ms': k3_avg_s * 1e3, 'algorithmic_flops_per_launch': flops_per_launch},
+                       'records_gathered': int(allrec.shape[0]), 'record_doubles': LD,
+                       'all_solved': bool(q[2] == 0 and q[0] == 0), 'statuses_last_step': {int(k): int(v) for k, v in zip(*np.unique(status_all, return_counts=True))},
+                       'timed_solves': int(q[1]), 'not_solved_in_timed_solves': int(q[2]), 'max_iter_in_timed_solves': int(q[3]),
+                       'err_bits_all_timed_steps': int(q[0]) | int(np.bitwise_or.reduce(err_all)),
+                       'mean_ipm_iterations': (it1 - it0) / max(1, (hi - lo) * args.steps * args.repeats)},
+            'roofline': roof,
         }
         if gait_stats is not None:
             out['gait'] = gait_stats
         if cl_stats is not None:
             out['closed_loop'] = cl_stats
         if world == 1 and not args.no_cpu_baseline and args.workload == 'B':
-            out['cpu_baseline'] = cpu_baseline(cfg)
+            try:
+                out['cpu_baseline'] = cpu_baseline(cfg)
+            except Exception as e:            # the GPU line stands on its own
+                out['cpu_baseline'] = {'value': None, 'unit': 'it/s', 'cores': 0, 'kind': 'port', 'sample': 'failed: %s' % e}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

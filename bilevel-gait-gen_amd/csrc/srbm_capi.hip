@@ -34,15 +34,61 @@ struct srbm_batch {
     std::vector<hipEvent_t> ev_start, ev_stop;
     std::vector<int> ev_steps;        // RTI steps covered by each timed launch (1 for the stand-alone IPM kernel)
     size_t ev_used = 0;
+    int gait_refs = 0;               // live srbm_gait handles borrowing this batch (and its stream)
+    void* d_scratch = nullptr;       // staging buffer of the small host->device entry points (grown on demand, never per call)
+    size_t scratch_bytes = 0;
 };
+static int batch_scratch(srbm_batch* h, size_t bytes, void** out) {
+    if (bytes > h->scratch_bytes) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->d_scratch) HIPCHK(hipFree(h->d_scratch));
+        h->d_scratch = nullptr; h->scratch_bytes = 0;
+        HIPCHK(hipMalloc(&h->d_scratch, bytes));
+        h->scratch_bytes = bytes;
+    }
+    *out = h->d_scratch;
+    return 0;
+}
 
 __global__ void srbm_k_pack_results(const SrbmParams* __restrict__ Pp, const SrbmInst* __restrict__ insts, const SrbmWork* __restrict__ works,
                                     double* __restrict__ out, int ld) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const SrbmInst& I = insts[b];
+    const int N = Pp->N, NX = 12 * (N + 1) + SRBM_NUMAX, NM = 12 * (N + 1) + 6 * SRBM_NSMAX + 16 * (N - 3) + 16;
     double* o = out + (size_t)b * ld;
-    if (tid == 0) { o[0] = I.status; o[1] = I.n; o[2] = I.m; o[3] = I.cost; o[4] = I.alpha; o[5] = I.err; o[6] = I.qp_iters; o[7] = I.init_time; }
-    for (int i = tid; i < I.n && 8 + i < ld; i += blockDim.x) o[8 + i] = works[b].x[i];
+    if (tid == 0) { o[0] = I.status; o[1] = I.n; o[2] = I.m; o[3] = I.cost; o[4] = I.alpha; o[5] = I.err_acc | I.err; o[6] = I.qp_iters; o[7] = I.init_time; }
+    for (int i = tid; i < NX && 8 + i < ld; i += blockDim.x) o[8 + i] = i < I.n ? works[b].x[i] : 0.0;
+    for (int i = tid; i < NM && 8 + NX + i < ld; i += blockDim.x) o[8 + NX + i] = i < I.m ? works[b].z[i] : 0.0;
+    // contact times (Trajectory::GetContactTimes): counts of the four feet, then 8 slots per foot
+    const int oc = 8 + NX + NM;
+    if (tid < SRBM_NEE && oc + 4 + 8 * SRBM_NEE <= ld) {
+        int n = 0;
+        for (int i = 0; i < I.nk[tid]; i++)
+            if (I.kind[tid][i] <= SRBM_K_TD) { if (n < 8) o[oc + 4 + 8 * tid + n] = I.knot_t[tid][i]; n++; }
+        o[oc + tid] = n;
+        for (int i = n; i < 8; i++) o[oc + 4 + 8 * tid + i] = 0.0;
+    }
+}
+
+// Trajectory::GetForce / GetEndEffectorLocation / GetContacts of the current trajectory at time[b] (trajectory.cpp:395-410, :70-80)
+__global__ void srbm_k_eval_trajectory(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, const double* __restrict__ time,
+                                       double* __restrict__ force, double* __restrict__ pos, int* __restrict__ in_contact) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= Pp->batch * SRBM_NEE) return;
+    const int b = w / SRBM_NEE, ee = w % SRBM_NEE;
+    SrbmInst& I = insts[b];
+    const FootView f{I.knot_t[ee], I.kind[ee], I.nk[ee]};
+    int err = 0;
+    const double t = time[b];
+    double F[3], xy[2];
+    srbm_force_value(f, &I.fval[ee][0][0][0], t, F, &err);
+    srbm_posxy_value(f, &I.pval[ee][0][0], t, xy, &err);
+    const double z = srbm_posz_value(f, t, Pp->swing_height, Pp->foot_offset, &err);
+    const int lo = srbm_lower(f, SEL_POSXY, t, &err), up = srbm_upper(f, SEL_POSXY, t, &err);
+    for (int c = 0; c < 3; c++) force[(size_t)w * 3 + c] = F[c];
+    pos[(size_t)w * 3] = xy[0]; pos[(size_t)w * 3 + 1] = xy[1]; pos[(size_t)w * 3 + 2] = z;
+    in_contact[w] = (f.kind[lo] == SRBM_K_TD && f.kind[up] == SRBM_K_LO) ? 1 : 0;      // EndEffectorSplines::IsInContact (:805-813)
+    if (err) atomicOr(&I.err, err);
 }
 
 // ---------------- small device kernels of the host protocol ----------------
@@ -90,6 +136,7 @@ __global__ void srbm_k_init(const SrbmParams* __restrict__ Pp, SrbmInst* __restr
     I.init_time = 0; I.alpha = 0; I.cost = 0; I.eq_violation = 0; I.step_norm = 0; I.qp_cost = 0; I.res_primal = 0; I.res_dual = 0; I.gap = 0;
     I.status = SRBM_UNSOLVED; I.qp_iters = 0; I.n = 0; I.m = 0; I.n_eq = 0; I.n_ineq = 0; I.nfv = 0; I.npv = 0; I.n_td = 0; I.n_samples = 0;
     I.err = 0; I.run_num = 0; I.acc_iters = 0; I.acc_flops = 0;
+    I.cost_sum = 0; I.acc_mfma = 0; I.err_acc = 0; I.n_solves = 0; I.n_not_solved = 0; I.n_maxiter = 0;
 }
 
 __global__ void srbm_k_warm_start(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, const double* __restrict__ states) {
@@ -224,6 +271,7 @@ static int launch_step(srbm_batch* h) {
 
 extern "C" {
 
+static int fetch_insts(srbm_batch* h, std::vector<SrbmInst>& v);
 const char* srbm_last_error(void) { return g_err.c_str(); }
 long srbm_bytes_per_instance(void) { return (long)(sizeof(SrbmInst) + sizeof(SrbmWork)); }
 /* diagnostic builds (-DSRBM_PROFILE) only: cycles per IPM phase of one instance, 16 slots */
@@ -329,9 +377,47 @@ int srbm_debug_get_trace(srbm_batch* h, int inst, double* out256) {
     return 0;
 }
 
+// device buffers + kernel attributes of a batch whose host parameters (h->hp, batch, device) are set; on failure everything
+// allocated so far is released by the caller through free_batch()
+static void free_batch(srbm_batch* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->dp); (void)hipFree(h->insts); (void)hipFree(h->works);
+    (void)hipFree(h->d_state); (void)hipFree(h->d_time); (void)hipFree(h->d_ee);
+    (void)hipFree(h->d_plant); (void)hipFree(h->d_push_time); (void)hipFree(h->d_push_impulse);
+    (void)hipFree(h->d_scratch);
+    for (auto e : h->ev_start) (void)hipEventDestroy(e);
+    for (auto e : h->ev_stop) (void)hipEventDestroy(e);
+    if (h->owns_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+static int alloc_batch(srbm_batch* h, hipStream_t borrowed_stream) {
+    const size_t B = h->batch;
+    if (borrowed_stream) { h->stream = borrowed_stream; h->owns_stream = false; }
+    else { HIPCHK(hipStreamCreate(&h->stream)); h->owns_stream = true; }
+    HIPCHK(hipMalloc(&h->dp, sizeof(SrbmParams)));
+    HIPCHK(hipMalloc(&h->insts, sizeof(SrbmInst) * B));
+    HIPCHK(hipMalloc(&h->works, sizeof(SrbmWork) * B));
+    HIPCHK(hipMalloc(&h->d_state, sizeof(double) * 13 * B));
+    HIPCHK(hipMalloc(&h->d_time, sizeof(double) * B));
+    HIPCHK(hipMalloc(&h->d_ee, sizeof(double) * 12 * B));
+    // the IPM kernel gets the whole LDS of a CU: what its fixed map leaves over holds the dense state rows (K3Smem::sig_row)
+    h->k3_lds = K3_LDS_LAUNCH_BYTES;
+    if (srbm_k3_lds_bytes(h->hp.N) > h->k3_lds) return fail("srbm_batch_create: LDS map exceeds 160 KB");
+    h->hp.lds_doubles = (int)(h->k3_lds / sizeof(double));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_ipm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_ipm_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_rti_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_rti_fused_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_normal_matrix), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
+    h->params_dirty = true;
+    return 0;
+}
+
 int srbm_batch_create(srbm_batch** out, int batch, const srbm_mpc_info* info, const srbm_model* model, int device) {
     if (!out || !info || !model || batch <= 0) return fail("srbm_batch_create: bad arguments");
-    if (info->num_nodes < 5 || info->num_nodes > SRBM_NMAX) return fail("srbm_batch_create: num_nodes must be in [5, 50]");
+    if (info->num_nodes < 5 || info->num_nodes > SRBM_NMAX) return fail("srbm_batch_create: num_nodes must be in [5, " + std::to_string(SRBM_NMAX) + "]");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("srbm_batch_create: no HIP device (this library has no CPU path)");
     HIPCHK(hipSetDevice(device));
@@ -353,44 +439,55 @@ int srbm_batch_create(srbm_batch** out, int batch, const srbm_mpc_info* info, co
         p.hip[2 * ee] = x; p.hip[2 * ee + 1] = y;
     }
     p.merit_mu = 5000; p.td_fraction = 0.75;
-    // ClarabelInterface::ConfigureForInitialRun / ConfigureForSolve (clarabel_interface.cpp:165-175) run every solve of the
-    // reference at tol_gap 1e-15, tol_feas 1e-10.  1e-15 is below the fp64 noise floor of this QP (the gap stops improving
-    // around 1e-13..1e-14 for the reference's solver restatement as well), so the default here is 1e-13: same minimiser to
-    // the 1e-4 the path is specified to, without the iterations spent detecting the stall.  srbm_set_solver_tolerances overrides.
-    p.tol_gap_abs = 1e-13; p.tol_gap_rel = 1e-13; p.tol_feas = 1e-10;
-    HIPCHK(hipStreamCreate(&h->stream));
-    HIPCHK(hipMalloc(&h->dp, sizeof(SrbmParams)));
-    HIPCHK(hipMalloc(&h->insts, sizeof(SrbmInst) * (size_t)batch));
-    HIPCHK(hipMalloc(&h->works, sizeof(SrbmWork) * (size_t)batch));
-    HIPCHK(hipMalloc(&h->d_state, sizeof(double) * 13 * (size_t)batch));
-    HIPCHK(hipMalloc(&h->d_time, sizeof(double) * (size_t)batch));
-    HIPCHK(hipMalloc(&h->d_ee, sizeof(double) * 12 * (size_t)batch));
-    HIPCHK(hipMemsetAsync(h->works, 0, sizeof(SrbmWork) * (size_t)batch, h->stream));
-    // the IPM kernel gets the whole LDS of a CU: what its fixed map leaves over holds the dense state rows (K3Smem::sig_row)
-    h->k3_lds = K3_LDS_LAUNCH_BYTES;
-    if (srbm_k3_lds_bytes(p.N) > h->k3_lds) { delete h; return fail("srbm_batch_create: LDS map exceeds 160 KB"); }
-    p.lds_doubles = (int)(h->k3_lds / sizeof(double));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_ipm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_ipm_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_rti_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_rti_fused_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
-    if (upload_params(h)) { delete h; return -1; }
+    // ClarabelInterface::ConfigureForInitialRun / ConfigureForRealTime (clarabel_interface.cpp:165-175) run every solve of the
+    // reference at tol_gap 1e-15, tol_feas 1e-10: the defaults here.  The gap of this QP stops improving around 1e-14..1e-15
+    // in fp64 (the loop then ends on its progress test), but WHERE it stops decides how well the minimiser is determined along
+    // the flat directions of the weakly convex QP: measured against the oracle on identical QPs (scripts/dev_accuracy.py,
+    // 1024 solves) the worst relative primal error is 1.3e-4 at 1e-13, 5e-5 at 1e-14 and 1.4e-5 at 1e-15, for 17.3 / 18.0 /
+    // 18.9 IPM iterations per solve.  The parity tolerance of the path is 1e-4.  srbm_set_solver_tolerances overrides.
+    p.tol_gap_abs = 1e-15; p.tol_gap_rel = 1e-15; p.tol_feas = 1e-10;
+    auto bail = [&]() { free_batch(h); return -1; };
+    if (alloc_batch(h, nullptr)) return bail();
+    if (hipMemsetAsync(h->works, 0, sizeof(SrbmWork) * (size_t)batch, h->stream) != hipSuccess) { fail("srbm_batch_create: memset failed"); return bail(); }
+    if (upload_params(h)) return bail();
     hipLaunchKernelGGL(srbm_k_init, dim3((batch + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { fail("srbm_batch_create: initialisation kernel failed"); return bail(); }
     *out = h;
     return 0;
 }
 
+// MPC::MPC(const MPC&) (mpc.cpp:1133-1181): a deep copy with its own stream and buffers
+int srbm_batch_clone(const srbm_batch* src, srbm_batch** out) {
+    if (!src || !out) return fail("srbm_batch_clone: bad arguments");
+    HIPCHK(hipSetDevice(src->device));
+    HIPCHK(hipStreamSynchronize(src->stream));
+    auto* h = new srbm_batch;
+    h->batch = src->batch; h->device = src->device; h->hp = src->hp; h->push_set = src->push_set;
+    auto bail = [&]() { free_batch(h); return -1; };
+    if (alloc_batch(h, nullptr)) return bail();
+    const size_t B = h->batch;
+    auto cp = [&](void* d, const void* s_, size_t n) { return hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, h->stream) == hipSuccess; };
+    bool ok = cp(h->insts, src->insts, sizeof(SrbmInst) * B) && cp(h->works, src->works, sizeof(SrbmWork) * B) &&
+              cp(h->d_state, src->d_state, sizeof(double) * 13 * B) && cp(h->d_time, src->d_time, sizeof(double) * B) &&
+              cp(h->d_ee, src->d_ee, sizeof(double) * 12 * B);
+    if (ok && src->d_plant) {
+        ok = hipMalloc(&h->d_plant, sizeof(double) * 13 * B) == hipSuccess && hipMalloc(&h->d_push_time, sizeof(double) * B) == hipSuccess &&
+             hipMalloc(&h->d_push_impulse, sizeof(double) * 6 * B) == hipSuccess && cp(h->d_plant, src->d_plant, sizeof(double) * 13 * B) &&
+             cp(h->d_push_time, src->d_push_time, sizeof(double) * B) && cp(h->d_push_impulse, src->d_push_impulse, sizeof(double) * 6 * B);
+    }
+    if (!ok) { fail("srbm_batch_clone: device copy failed"); return bail(); }
+    if (upload_params(h)) return bail();
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { fail("srbm_batch_clone: synchronisation failed"); return bail(); }
+    *out = h;
+    return 0;
+}
+int srbm_batch_size(const srbm_batch* h) { return h ? h->batch : -1; }
+int srbm_num_nodes(const srbm_batch* h) { return h ? h->hp.N : -1; }
+
 int srbm_batch_destroy(srbm_batch* h) {
     if (!h) return 0;
-    (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
-    (void)hipFree(h->dp); (void)hipFree(h->insts); (void)hipFree(h->works);
-    (void)hipFree(h->d_state); (void)hipFree(h->d_time); (void)hipFree(h->d_ee);
-    (void)hipFree(h->d_plant); (void)hipFree(h->d_push_time); (void)hipFree(h->d_push_impulse);
-    if (h->owns_stream) (void)hipStreamDestroy(h->stream);
-    delete h;
+    if (h->gait_refs > 0) return fail("srbm_batch_destroy: srbm_gait handles still borrow this batch (destroy them first)");
+    free_batch(h);
     return 0;
 }
 
@@ -557,16 +654,29 @@ void* srbm_stream(srbm_batch* h) { return h ? (void*)h->stream : nullptr; }
 int srbm_update_contact_times(srbm_batch* h, const double* times, int max_contacts) {
     if (!h || !times || max_contacts <= 0) return fail("bad arguments");
     HIPCHK(hipSetDevice(h->device));
-    double* d = nullptr;
+    // the reference indexes the caller's vector with its own contact count (end_effector_splines.cpp:860-892): a vector that is
+    // too short is an out-of-range read there, an error here
+    std::vector<SrbmInst> v;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    v.resize(h->batch);
+    HIPCHK(hipMemcpy(v.data(), h->insts, sizeof(SrbmInst) * (size_t)h->batch, hipMemcpyDeviceToHost));
+    for (int b = 0; b < h->batch; b++)
+        for (int ee = 0; ee < SRBM_NEE; ee++) {
+            int n = 0;
+            for (int i = 0; i < v[b].nk[ee]; i++) n += (v[b].kind[ee][i] <= SRBM_K_TD);
+            if (n > max_contacts)
+                return fail("srbm_update_contact_times: instance " + std::to_string(b) + " foot " + std::to_string(ee) + " has " + std::to_string(n) +
+                            " contact times, max_contacts is " + std::to_string(max_contacts));
+        }
+    void* d = nullptr;
     const size_t bytes = sizeof(double) * (size_t)h->batch * SRBM_NEE * max_contacts;
-    HIPCHK(hipMalloc(&d, bytes));
+    if (batch_scratch(h, bytes, &d)) return -1;
     HIPCHK(hipMemcpyAsync(d, times, bytes, hipMemcpyHostToDevice, h->stream));
     if (upload_params(h)) return -1;
     const int tot = h->batch * SRBM_NEE;
-    hipLaunchKernelGGL(srbm_k_set_contact_times, dim3((tot + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts, d, max_contacts);
+    hipLaunchKernelGGL(srbm_k_set_contact_times, dim3((tot + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts, static_cast<const double*>(d), max_contacts);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipFree(d));
     return 0;
 }
 
@@ -585,26 +695,27 @@ static int make_candidate_batch(const srbm_batch* h, srbm_batch** out) {
     auto* c = new srbm_batch;
     c->batch = h->batch * SRBM_LS_SIZE; c->device = h->device;
     c->hp = h->hp; c->hp.batch = c->batch;
-    c->stream = h->stream; c->owns_stream = false;
-    c->k3_lds = h->k3_lds;
-    const size_t B = c->batch;
-    HIPCHK(hipMalloc(&c->dp, sizeof(SrbmParams)));
-    HIPCHK(hipMalloc(&c->insts, sizeof(SrbmInst) * B));
-    HIPCHK(hipMalloc(&c->works, sizeof(SrbmWork) * B));
-    HIPCHK(hipMalloc(&c->d_state, sizeof(double) * 13 * B));
-    HIPCHK(hipMalloc(&c->d_time, sizeof(double) * B));
-    HIPCHK(hipMalloc(&c->d_ee, sizeof(double) * 12 * B));
-    HIPCHK(hipMemsetAsync(c->works, 0, sizeof(SrbmWork) * B, c->stream));
+    if (alloc_batch(c, h->stream) || hipMemsetAsync(c->works, 0, sizeof(SrbmWork) * (size_t)c->batch, c->stream) != hipSuccess) {
+        free_batch(c);
+        return g_err.empty() ? fail("candidate batch: allocation failed") : -1;
+    }
     *out = c;
     return 0;
 }
-
-int srbm_gait_create(srbm_batch* h, srbm_gait** out) {
-    if (!h || !out) return fail("bad arguments");
-    HIPCHK(hipSetDevice(h->device));
-    auto* g = new srbm_gait;
-    g->h = h;
-    if (make_candidate_batch(h, &g->ls)) { delete g; return -1; }
+static void free_gait(srbm_gait* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->h->device);
+    (void)hipStreamSynchronize(g->h->stream);
+    if (g->ls) free_batch(g->ls);                    // (borrows the batch's stream: released before the batch, enforced by gait_refs)
+    (void)hipFree(g->xk); (void)hipFree(g->step); (void)hipFree(g->dHdth); (void)hipFree(g->costs);
+    (void)hipFree(g->counts); (void)hipFree(g->imin); (void)hipFree(g->gw); (void)hipFree(g->valid); (void)hipFree(g->lp_status);
+    (void)hipFree(g->pred_red); (void)hipFree(g->ready);
+    g->h->gait_refs--;
+    delete g;
+}
+static int alloc_gait(srbm_gait* g) {
+    srbm_batch* h = g->h;
+    if (make_candidate_batch(h, &g->ls)) return -1;
     const size_t B = h->batch;
     HIPCHK(hipMalloc(&g->xk, sizeof(double) * SRBM_GAIT_NV * B));
     HIPCHK(hipMalloc(&g->step, sizeof(double) * SRBM_GAIT_NV * B));
@@ -616,28 +727,32 @@ int srbm_gait_create(srbm_batch* h, srbm_gait** out) {
     HIPCHK(hipMalloc(&g->lp_status, sizeof(int) * B));
     HIPCHK(hipMalloc(&g->pred_red, sizeof(double) * B));
     HIPCHK(hipMalloc(&g->ready, sizeof(int) * B));
+    HIPCHK(hipMalloc(&g->gw, sizeof(SrbmGaitWork) * B));
     HIPCHK(hipMemsetAsync(g->ready, 0, sizeof(int) * B, h->stream));
     HIPCHK(hipMemsetAsync(g->lp_status, 0, sizeof(int) * B, h->stream));
     HIPCHK(hipMemsetAsync(g->pred_red, 0, sizeof(double) * B, h->stream));
     HIPCHK(hipMemsetAsync(g->valid, 0, sizeof(int) * B, h->stream));
-    HIPCHK(hipMalloc(&g->gw, sizeof(SrbmGaitWork) * B));
+    HIPCHK(hipMemsetAsync(g->counts, 0, sizeof(int) * SRBM_NEE * B, h->stream));
     HIPCHK(hipMemsetAsync(g->gw, 0, sizeof(SrbmGaitWork) * B, h->stream));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_normal_matrix), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
     HIPCHK(hipMemsetAsync(g->xk, 0, sizeof(double) * SRBM_GAIT_NV * B, h->stream));
     HIPCHK(hipMemsetAsync(g->step, 0, sizeof(double) * SRBM_GAIT_NV * B, h->stream));
     HIPCHK(hipMemsetAsync(g->dHdth, 0, sizeof(double) * SRBM_GAIT_NV * B, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int srbm_gait_create(srbm_batch* h, srbm_gait** out) {
+    if (!h || !out) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    auto* g = new srbm_gait;
+    g->h = h;
+    h->gait_refs++;
+    if (alloc_gait(g)) { free_gait(g); return -1; }
     *out = g;
     return 0;
 }
 int srbm_gait_destroy(srbm_gait* g) {
-    if (!g) return 0;
-    (void)hipSetDevice(g->h->device);
-    (void)hipStreamSynchronize(g->h->stream);
-    srbm_batch_destroy(g->ls);
-    (void)hipFree(g->xk); (void)hipFree(g->step); (void)hipFree(g->dHdth); (void)hipFree(g->costs);
-    (void)hipFree(g->counts); (void)hipFree(g->imin); (void)hipFree(g->gw); (void)hipFree(g->valid); (void)hipFree(g->lp_status); (void)hipFree(g->pred_red); (void)hipFree(g->ready);
-    delete g;
+    free_gait(g);
     return 0;
 }
 // GaitOptimizer::SetContactTimes(mpc.GetTrajectory().GetContactTimes()) (gait_optimizer.cpp:395-408)
@@ -706,15 +821,15 @@ int srbm_gait_get_sensitivity(srbm_gait* g, double* d, int ld) {
     if (!g || !d || ld <= 0) return fail("bad arguments");
     srbm_batch* h = g->h;
     HIPCHK(hipSetDevice(h->device));
-    double* dev = nullptr;
+    void* devv = nullptr;
     const size_t bytes = sizeof(double) * (size_t)h->batch * ld;
-    HIPCHK(hipMalloc(&dev, bytes));
+    if (batch_scratch(h, bytes, &devv)) return -1;
+    double* dev = static_cast<double*>(devv);
     HIPCHK(hipMemsetAsync(dev, 0, bytes, h->stream));
     hipLaunchKernelGGL(srbm_k_gait_pack_d, dim3(h->batch), dim3(128), 0, h->stream, h->dp, h->insts, h->works, g->gw, dev, ld);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(d, dev, bytes, hipMemcpyDeviceToHost));
-    HIPCHK(hipFree(dev));
     return 0;
 }
 // GaitOptimizer::OptimizeContactTimes (gait_optimizer.cpp:185-364): the LP over the contact-time step; time[batch]
@@ -810,7 +925,10 @@ int srbm_gait_rti_advance(srbm_gait* g, int first_run_num, int steps, int gait_o
 /* status / stats of the candidates of the last line search: status[batch][10], iters[batch][10] (diagnostic) */
 int srbm_gait_get_candidate_status(srbm_gait* g, int* status, int* err) {
     if (!g || !status || !err) return fail("bad arguments");
-    return srbm_get_status(g->ls, status, err);
+    std::vector<SrbmInst> v;
+    if (fetch_insts(g->ls, v)) return -1;
+    for (int b = 0; b < g->ls->batch; b++) { status[b] = v[b].status; err[b] = v[b].err | v[b].err_acc; }
+    return 0;
 }
 
 // MPC::AdjustForCurrentContacts (mpc.cpp:1195-1203): time[batch], in_contact[batch][4]
@@ -818,16 +936,16 @@ int srbm_adjust_for_current_contacts(srbm_batch* h, const double* time, const in
     if (!h || !time || !in_contact) return fail("bad arguments");
     HIPCHK(hipSetDevice(h->device));
     if (upload_params(h)) return -1;
-    int* dc = nullptr;
+    void* dcv = nullptr;
     const size_t B = h->batch;
-    HIPCHK(hipMalloc(&dc, sizeof(int) * 4 * B));
+    if (batch_scratch(h, sizeof(int) * 4 * B, &dcv)) return -1;
+    int* dc = static_cast<int*>(dcv);
     HIPCHK(hipMemcpyAsync(dc, in_contact, sizeof(int) * 4 * B, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_time, time, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
     const int tot = h->batch * SRBM_NEE;
     hipLaunchKernelGGL(srbm_k_adjust_for_current_contacts, dim3((tot + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts, h->d_time, dc);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipFree(dc));
     return 0;
 }
 
@@ -869,6 +987,18 @@ int srbm_pack_results_dev(srbm_batch* h, double* out_dev, int ld) {
     if (upload_params(h)) return -1;
     hipLaunchKernelGGL(srbm_k_pack_results, dim3(h->batch), dim3(64), 0, h->stream, h->dp, h->insts, h->works, out_dev, ld);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int srbm_pack_results(srbm_batch* h, double* out, int ld) {
+    if (!h || !out || ld < 8) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    void* d = nullptr;
+    const size_t bytes = sizeof(double) * (size_t)h->batch * ld;
+    if (batch_scratch(h, bytes, &d)) return -1;
+    if (srbm_pack_results_dev(h, static_cast<double*>(d), ld)) return -1;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, d, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1072,6 +1202,163 @@ int srbm_export_qp(srbm_batch* h, int inst, double* A, double* b, double* Pm, do
         for (int j = 0; j < W.nf; j++) Pm[(size_t)(nx + j) * n + nx + j] += P.force_cost;
         for (int i = 0; i < n; i++) Pm[(size_t)i * n + i] += 1e-3;
     }
+    return 0;
+}
+
+// ---------------- mpc::Trajectory as a flat record ----------------
+static void inst_to_record(const SrbmParams& P, const SrbmInst& I, srbm_trajectory* t) {
+    std::memset(t, 0, sizeof(*t));
+    t->num_states = P.N + 1;
+    t->init_time = I.init_time; t->node_dt = P.dt; t->swing_height = P.swing_height; t->foot_offset = P.foot_offset;
+    for (int k = 0; k <= P.N; k++) std::memcpy(t->states[k], &I.states[k * 13], sizeof(double) * 13);
+    for (int ee = 0; ee < SRBM_NEE; ee++) {
+        t->nk[ee] = I.nk[ee];
+        for (int k = 0; k < SRBM_KMAX; k++) { t->knot_kind[ee][k] = I.kind[ee][k]; t->knot_time[ee][k] = I.knot_t[ee][k]; }
+    }
+    static_assert(SRBM_TRAJ_KMAX == SRBM_KMAX, "record and device knot capacity agree");
+    std::memcpy(t->force, I.fval, sizeof(I.fval));
+    std::memcpy(t->pos_xy, I.pval, sizeof(I.pval));
+}
+static const char* check_record(const SrbmParams& P, const srbm_trajectory& t) {
+    if (t.num_states != P.N + 1) return "num_states != num_nodes + 1";
+    for (int ee = 0; ee < SRBM_NEE; ee++) {
+        if (t.nk[ee] < 2 || t.nk[ee] > SRBM_KMAX) return "knot count out of range";
+        int contacts = 0;
+        for (int k = 0; k < t.nk[ee]; k++) {
+            if (t.knot_kind[ee][k] < 0 || t.knot_kind[ee][k] > SRBM_K_MID) return "unknown knot kind";
+            if (k > 0 && !(t.knot_time[ee][k] >= t.knot_time[ee][k - 1])) return "knot times must be non-decreasing";
+            contacts += t.knot_kind[ee][k] <= SRBM_K_TD;
+        }
+        if (contacts < 2) return "a foot needs at least two contact knots";
+        if (t.knot_kind[ee][0] > SRBM_K_TD) return "the first knot of a foot must be a contact knot";
+    }
+    return nullptr;
+}
+int srbm_sizeof_trajectory(void) { return (int)sizeof(srbm_trajectory); }
+int srbm_get_trajectory(srbm_batch* h, int first, int count, srbm_trajectory* out) {
+    if (!h || !out || first < 0 || count < 0 || first + count > h->batch) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<SrbmInst> v(count);
+    HIPCHK(hipMemcpy(v.data(), h->insts + first, sizeof(SrbmInst) * (size_t)count, hipMemcpyDeviceToHost));
+    for (int i = 0; i < count; i++) inst_to_record(h->hp, v[i], out + i);
+    return 0;
+}
+// MPC::SetWarmStartTrajectory (mpc.cpp:110-119)
+int srbm_set_warm_start_trajectory(srbm_batch* h, int first, int count, const srbm_trajectory* trajs) {
+    if (!h || !trajs || first < 0 || count < 0 || first + count > h->batch) return fail("bad arguments");
+    for (int i = 0; i < count; i++)
+        if (const char* why = check_record(h->hp, trajs[i])) return fail("srbm_set_warm_start_trajectory: record " + std::to_string(i) + ": " + why);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<SrbmInst> v(count);
+    HIPCHK(hipMemcpy(v.data(), h->insts + first, sizeof(SrbmInst) * (size_t)count, hipMemcpyDeviceToHost));
+    for (int i = 0; i < count; i++) {
+        SrbmInst& I = v[i];
+        const srbm_trajectory& t = trajs[i];
+        for (int k = 0; k <= h->hp.N; k++) std::memcpy(&I.states[k * 13], t.states[k], sizeof(double) * 13);
+        for (int ee = 0; ee < SRBM_NEE; ee++) {
+            I.nk[ee] = t.nk[ee];
+            for (int k = 0; k < SRBM_KMAX; k++) {
+                const bool in = k < t.nk[ee];
+                I.kind[ee][k] = in ? (uint8_t)t.knot_kind[ee][k] : 0; I.knot_t[ee][k] = in ? t.knot_time[ee][k] : 0.0;
+            }
+        }
+        std::memcpy(I.fval, t.force, sizeof(I.fval));
+        std::memcpy(I.pval, t.pos_xy, sizeof(I.pval));
+        I.init_time = t.init_time;              // init_time_ = trajectory.GetTime(0)
+    }
+    HIPCHK(hipMemcpy(h->insts + first, v.data(), sizeof(SrbmInst) * (size_t)count, hipMemcpyHostToDevice));
+    return 0;
+}
+// Trajectory::GetForce / GetEndEffectorLocation / EndEffectorSplines::IsInContact on a record: host arithmetic, the same
+// functions the kernels use (srbm_spline.hiph is host + device)
+int srbm_trajectory_eval(const srbm_trajectory* t, int ee, double time, double* force3, double* pos3, int* in_contact) {
+    if (!t || ee < 0 || ee >= SRBM_NEE) return fail("bad arguments");
+    if (t->nk[ee] < 2 || t->nk[ee] > SRBM_KMAX) return fail("srbm_trajectory_eval: malformed record");
+    uint8_t kind[SRBM_KMAX];
+    for (int k = 0; k < SRBM_KMAX; k++) kind[k] = (uint8_t)t->knot_kind[ee][k];
+    const FootView f{t->knot_time[ee], kind, t->nk[ee]};
+    int err = 0;
+    if (force3) srbm_force_value(f, &t->force[ee][0][0][0], time, force3, &err);
+    if (pos3) {
+        srbm_posxy_value(f, &t->pos_xy[ee][0][0], time, pos3, &err);
+        pos3[2] = srbm_posz_value(f, time, t->swing_height, t->foot_offset, &err);
+    }
+    if (in_contact) {
+        const int lo = srbm_lower(f, SEL_POSXY, time, &err), up = srbm_upper(f, SEL_POSXY, time, &err);
+        *in_contact = (kind[lo] == SRBM_K_TD && kind[up] == SRBM_K_LO) ? 1 : 0;
+    }
+    return err;
+}
+int srbm_eval_trajectory(srbm_batch* h, const double* time, double* force, double* pos, int* in_contact) {
+    if (!h || !time) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    const size_t B = h->batch, nf = sizeof(double) * 12 * B;
+    void* dv = nullptr;
+    if (batch_scratch(h, sizeof(double) * B + 2 * nf + sizeof(int) * 4 * B, &dv)) return -1;
+    double* d_t = static_cast<double*>(dv);
+    double* d_f = d_t + B;
+    double* d_p = d_f + 12 * B;
+    int* d_c = reinterpret_cast<int*>(d_p + 12 * B);
+    HIPCHK(hipMemcpyAsync(d_t, time, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+    const int tot = h->batch * SRBM_NEE;
+    hipLaunchKernelGGL(srbm_k_eval_trajectory, dim3((tot + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts, d_t, d_f, d_p, d_c);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (force) HIPCHK(hipMemcpy(force, d_f, nf, hipMemcpyDeviceToHost));
+    if (pos) HIPCHK(hipMemcpy(pos, d_p, nf, hipMemcpyDeviceToHost));
+    if (in_contact) HIPCHK(hipMemcpy(in_contact, d_c, sizeof(int) * 4 * B, hipMemcpyDeviceToHost));
+    return 0;
+}
+int srbm_get_ee_box_center(const srbm_batch* h, double* centers) {
+    if (!h || !centers) return fail("bad arguments");
+    std::memcpy(centers, h->hp.hip, sizeof(double) * 8);
+    return 0;
+}
+int srbm_get_cost(srbm_batch* h, double* cost) {
+    if (!h || !cost) return fail("bad arguments");
+    std::vector<SrbmInst> v;
+    if (fetch_insts(h, v)) return -1;
+    for (int b = 0; b < h->batch; b++) cost[b] = v[b].cost;
+    return 0;
+}
+int srbm_get_avg_cost(srbm_batch* h, double* avg) {
+    if (!h || !avg) return fail("bad arguments");
+    std::vector<SrbmInst> v;
+    if (fetch_insts(h, v)) return -1;
+    for (int b = 0; b < h->batch; b++) avg[b] = v[b].cost_sum / v[b].run_num;      // (0/0 = NaN before the first solve, as the reference's)
+    return 0;
+}
+int srbm_get_status_accumulated(srbm_batch* h, int* acc) {
+    if (!h || !acc) return fail("bad arguments");
+    std::vector<SrbmInst> v;
+    if (fetch_insts(h, v)) return -1;
+    for (int b = 0; b < h->batch; b++) { acc[4 * b] = v[b].err_acc | v[b].err; acc[4 * b + 1] = v[b].n_solves; acc[4 * b + 2] = v[b].n_not_solved; acc[4 * b + 3] = v[b].n_maxiter; }
+    return 0;
+}
+__global__ void srbm_k_clear_acc(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= Pp->batch) return;
+    insts[b].err_acc = 0; insts[b].n_solves = 0; insts[b].n_not_solved = 0; insts[b].n_maxiter = 0;
+}
+int srbm_clear_status_accumulators(srbm_batch* h) {
+    if (!h) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    hipLaunchKernelGGL(srbm_k_clear_acc, dim3((h->batch + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int srbm_result_record_doubles(int N) { return 8 + 12 * (N + 1) + SRBM_NUMAX + 12 * (N + 1) + 6 * SRBM_NSMAX + 16 * (N - 3) + 16 + 36; }
+int srbm_get_executed_mfma(srbm_batch* h, double* total) {
+    if (!h || !total) return fail("bad arguments");
+    std::vector<SrbmInst> v;
+    if (fetch_insts(h, v)) return -1;
+    double t = 0;
+    for (auto& I : v) t += I.acc_mfma;
+    *total = t;
     return 0;
 }
 

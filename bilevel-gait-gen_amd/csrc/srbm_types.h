@@ -57,6 +57,12 @@ typedef struct SrbmInst {
     uint8_t kind[SRBM_NEE][SRBM_KMAX];
     int status, qp_iters, n, m, n_eq, n_ineq, nfv, npv, n_td, n_samples, err, run_num;
     double acc_iters, acc_flops;                  /* running totals: IPM iterations, algorithmic flops (SURVEY.md 8d formula) */
+    /* sticky accumulators over ALL solves since srbm_clear_status_accumulators: `err` / `status` describe the last solve only
+       (kernel 1 restarts them), these keep every error bit raised and count the solves by outcome; cost_sum / n_solves is
+       MPC::GetAvgCost (mpc.cpp:991-998: mean of the cost_ entries RecordStats pushes, one per solve) */
+    double cost_sum;
+    double acc_mfma;                              /* v_mfma_f64_16x16x4_f64 instructions EXECUTED (per wave) by the condensing and IPM phases: the executed-flop side of the roofline */
+    int err_acc, n_solves, n_not_solved, n_maxiter;       /* n_not_solved: status not in {Solved, SolvedInacc}; n_maxiter: of those, MaxIter */
 } SrbmInst;
 
 /* per (node, foot) linearisation record */

@@ -32,6 +32,48 @@ class Model(C.Structure):            # srbm_model
     _fields_ = [('mass', C.c_double), ('Ir', C.c_double * 9), ('hip_xy', C.c_double * 8)]
 
 
+KMAX, NODES_MAX = 32, 101
+
+
+class Trajectory(C.Structure):       # srbm_trajectory: mpc::Trajectory as a flat record (include/srbm_rti.h)
+    _fields_ = [('num_states', C.c_int), ('nk', C.c_int * 4), ('knot_kind', (C.c_int * KMAX) * 4),
+                ('init_time', C.c_double), ('node_dt', C.c_double), ('swing_height', C.c_double), ('foot_offset', C.c_double),
+                ('states', (C.c_double * 13) * NODES_MAX), ('knot_time', (C.c_double * KMAX) * 4),
+                ('force', (((C.c_double * 2) * KMAX) * 3) * 4), ('pos_xy', ((C.c_double * KMAX) * 2) * 4)]
+
+    # ---- the part of mpc::Trajectory's interface the caller uses (controllers/mpc_controller.cpp:171-186,415-509) ----
+    def get_time(self, node):                      # Trajectory::GetTime (trajectory.cpp:412-414)
+        return self.init_time + self.node_dt * node
+
+    def get_node(self, time):                      # Trajectory::GetNode (trajectory.cpp:479-481)
+        return int(np.ceil((time - self.init_time) / self.node_dt))
+
+    def get_states(self):
+        return np.ctypeslib.as_array(self.states)[:self.num_states].copy()
+
+    def _eval(self, ee, time):
+        f = (C.c_double * 3)(); p = (C.c_double * 3)(); c = C.c_int(0)
+        rc = lib().srbm_trajectory_eval(C.byref(self), int(ee), C.c_double(time), f, p, C.byref(c))
+        if rc != 0:
+            raise RuntimeError('trajectory lookup failed at t=%g (error bits %d)' % (time, rc))   # the reference throws std::runtime_error
+        return np.array(f[:]), np.array(p[:]), bool(c.value)
+
+    def get_force(self, ee, time):                 # Trajectory::GetForce (trajectory.cpp:395-402)
+        return self._eval(ee, time)[0]
+
+    def get_end_effector_location(self, ee, time):     # Trajectory::GetEndEffectorLocation (trajectory.cpp:404-410)
+        return self._eval(ee, time)[1]
+
+    def get_contacts(self, time):                  # Trajectory::GetContacts
+        return [self._eval(ee, time)[2] for ee in range(4)]
+
+    def get_contact_times(self):                   # Trajectory::GetContactTimes: per foot the times of the LO / TD knots
+        out = []
+        for ee in range(4):
+            out.append([self.knot_time[ee][k] for k in range(self.nk[ee]) if self.knot_kind[ee][k] <= 1])
+        return out
+
+
 def build(force=False):
     """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
     if force or not os.path.exists(LIB_PATH):
@@ -158,6 +200,67 @@ class BatchMPC:
         if rc != 0:
             raise RuntimeError('srbm: ' + self.L.srbm_last_error().decode())
 
+    def clone(self):
+        """MPC copy constructor (mpc.cpp:1133-1181): a deep copy with its own stream and device buffers"""
+        c = object.__new__(BatchMPC)
+        c.L, c.cfg, c.batch, c.N = self.L, self.cfg, self.batch, self.N
+        c.h = C.c_void_p()
+        self._chk(self.L.srbm_batch_clone(self.h, C.byref(c.h)))
+        return c
+
+    # ---- mpc::Trajectory in and out ----
+    def get_trajectory(self, first=0, count=None):
+        """MPC::GetTrajectory for instances [first, first + count): a ctypes array of Trajectory records"""
+        count = self.batch - first if count is None else count
+        arr = (Trajectory * count)()
+        self._chk(self.L.srbm_get_trajectory(self.h, int(first), int(count), arr))
+        return arr
+
+    def set_warm_start_trajectory(self, trajs, first=0):
+        """MPC::SetWarmStartTrajectory (mpc.cpp:110-119); trajs: ctypes array (or list) of Trajectory records"""
+        if not isinstance(trajs, C.Array):
+            trajs = (Trajectory * len(trajs))(*trajs)
+        self._chk(self.L.srbm_set_warm_start_trajectory(self.h, int(first), len(trajs), trajs))
+
+    def eval_trajectory(self, time):
+        """Trajectory::GetForce / GetEndEffectorLocation / GetContacts of every instance's current trajectory at time[batch]"""
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(time, dtype=np.float64), (self.batch,)))
+        f = np.zeros((self.batch, 4, 3)); p = np.zeros((self.batch, 4, 3)); c = np.zeros((self.batch, 4), np.int32)
+        self._chk(self.L.srbm_eval_trajectory(self.h, _d(t), _d(f), _d(p), _i(c)))
+        return f, p, c
+
+    def ee_box_center(self):
+        a = np.zeros((4, 2))
+        self._chk(self.L.srbm_get_ee_box_center(self.h, _d(a)))
+        return a
+
+    def cost(self):
+        a = np.zeros(self.batch)
+        self._chk(self.L.srbm_get_cost(self.h, _d(a)))
+        return a
+
+    def avg_cost(self):
+        a = np.zeros(self.batch)
+        self._chk(self.L.srbm_get_avg_cost(self.h, _d(a)))
+        return a
+
+    def status_accumulated(self):
+        """sticky accumulators over all solves since the last clear: [batch][4] = error bits, solves, not-solved, of those MaxIter"""
+        a = np.zeros((self.batch, 4), np.int32)
+        self._chk(self.L.srbm_get_status_accumulated(self.h, _i(a)))
+        return a
+
+    def clear_status_accumulators(self):
+        self._chk(self.L.srbm_clear_status_accumulators(self.h))
+
+    def executed_mfma(self):
+        v = C.c_double(0)
+        self._chk(self.L.srbm_get_executed_mfma(self.h, C.byref(v)))
+        return v.value
+
+    def result_record_doubles(self):
+        return int(self.L.srbm_result_record_doubles(self.N))
+
     # ---- set-up (mpc.h:92-110) ----
     def add_quadratic_tracking_cost(self, state_des12, Q):
         a = np.ascontiguousarray(state_des12, dtype=np.float64); q = np.ascontiguousarray(Q, dtype=np.float64)
@@ -279,6 +382,13 @@ class BatchMPC:
 
     def pack_results_dev(self, ptr, ld):
         self._chk(self.L.srbm_pack_results_dev(self.h, C.c_void_p(ptr), int(ld)))
+
+    def pack_results(self):
+        """the result records of srbm_pack_results_dev in a host array [batch][srbm_result_record_doubles(N)]"""
+        ld = self.result_record_doubles()
+        a = np.zeros((self.batch, ld))
+        self._chk(self.L.srbm_pack_results(self.h, _d(a), ld))
+        return a
 
     # ---- results ----
     def sizes(self):

@@ -36,6 +36,13 @@ int srbm_batch_create(srbm_batch** out, int batch, const srbm_mpc_info* info, co
 int srbm_batch_destroy(srbm_batch* h);
 const char* srbm_last_error(void);
 
+/* value semantics of the reference object: MPC::MPC(const MPC&) / operator= (mpc/mpc.cpp:1133-1181, mpc_single_rigid_body.cpp:
+ * 804-807; the gait line search copies one MPC per thread, mpc/gait_optimizer.cpp:696).  The clone owns its own stream and
+ * device buffers and carries the complete state of `src` (parameters, costs, tolerances, trajectories, last QP, plant). */
+int srbm_batch_clone(const srbm_batch* src, srbm_batch** out);
+int srbm_batch_size(const srbm_batch* h);
+int srbm_num_nodes(const srbm_batch* h);
+
 /* MPC::AddQuadraticTrackingCost (mpc/mpc.cpp:533-540): Q 12x12 row-major, state_des in tangent coordinates (12) */
 int srbm_add_quadratic_tracking_cost(srbm_batch* h, const double* state_des12, const double* Q144);
 /* MPC::SetQuadraticFinalCost / SetLinearFinalCost (mpc/mpc.cpp:137-151) */
@@ -44,7 +51,7 @@ int srbm_set_linear_final_cost(srbm_batch* h, const double* w12);
 /* MPC::SetStateTrajectoryWarmStart (mpc/mpc.cpp:700-706): states[batch][13], replicated over the horizon */
 int srbm_set_state_trajectory_warm_start(srbm_batch* h, const double* states);
 /* ClarabelInterface tolerances (mpc/qp/clarabel_interface.cpp:18-27,165-175) for the on-device IPM.
- * Defaults: gap 1e-13 (the reference's 1e-15 is below the fp64 noise floor of this QP), feasibility 1e-10, 200 iterations */
+ * Defaults: the reference's own -- gap 1e-15, feasibility 1e-10 -- and 200 iterations (Clarabel's max_iter) */
 int srbm_set_solver_tolerances(srbm_batch* h, double tol_gap_abs, double tol_gap_rel, double tol_feas, int max_iter);
 
 /* MPC::CreateInitialRun (mpc/mpc.cpp:78-90): 10 solves at t = 0.   state[batch][13], ee[batch][4][3] */
@@ -80,6 +87,43 @@ int srbm_plant_set_push(srbm_batch* h, const double* time, const double* impulse
 int srbm_closed_loop_advance(srbm_batch* h, int first_index, int steps, int substeps, int advance_time);
 int srbm_synchronize(srbm_batch* h);
 void* srbm_stream(srbm_batch* h);            /* hipStream_t the kernels are launched on */
+
+/* ---- mpc::Trajectory as a flat record (mpc/include/trajectory.h:20-175): what MPC::GetTrajectory returns by value and
+ * MPC::SetWarmStartTrajectory takes.  Knot tables as srbm_get_knots: kind 0 lift-off, 1 touch-down, 2 stance-interior
+ * (force node with value + slope/FORCE_MULT), 3 mid-swing; force[ee][coord][knot] = {value, slope/100} (used on kind-2
+ * knots), pos_xy[ee][coord][knot] (used on kind-0/1 knots); z follows from swing_height / foot_offset
+ * (trajectory.cpp:303-317). */
+#define SRBM_TRAJ_KMAX 32
+#define SRBM_TRAJ_NODES_MAX 101          /* trajectory.h:165-166 */
+typedef struct srbm_trajectory {
+    int num_states;                       /* num_nodes + 1 */
+    int nk[4];
+    int knot_kind[4][SRBM_TRAJ_KMAX];
+    double init_time, node_dt, swing_height, foot_offset;
+    double states[SRBM_TRAJ_NODES_MAX][13];
+    double knot_time[4][SRBM_TRAJ_KMAX];
+    double force[4][3][SRBM_TRAJ_KMAX][2];
+    double pos_xy[4][2][SRBM_TRAJ_KMAX];
+} srbm_trajectory;
+/* sizeof(srbm_trajectory) as the library was compiled: bindings check their own struct layout against it */
+int srbm_sizeof_trajectory(void);
+/* MPC::GetTrajectory (mpc/mpc.cpp:1023-1025) for instances [first, first + count): out[count] */
+int srbm_get_trajectory(srbm_batch* h, int first, int count, srbm_trajectory* out);
+/* MPC::SetWarmStartTrajectory (mpc/mpc.cpp:110-119) for instances [first, first + count): prev_traj_ = trajectory,
+ * init_time_ = trajectory.GetTime(0).  The record is validated (knot counts, kinds, ordering); -1 on a malformed one. */
+int srbm_set_warm_start_trajectory(srbm_batch* h, int first, int count, const srbm_trajectory* trajs);
+/* Trajectory::GetForce / GetEndEffectorLocation / GetContacts at a time (mpc/trajectory.cpp:395-410, :70-80): pure host
+ * arithmetic on a record (no GPU needed) -- what controllers/mpc_controller.cpp:171-186,352,415-509 evaluates at 1 kHz.
+ * force[3], pos[3]; returns 0, or the error bits of the lookup (time outside the knot range: the reference throws). */
+int srbm_trajectory_eval(const srbm_trajectory* traj, int ee, double time, double* force3, double* pos3, int* in_contact);
+/* the same for the CURRENT trajectory of every instance on the device: time[batch] -> force[batch][4][3], pos[batch][4][3],
+ * in_contact[batch][4] (any output may be NULL) */
+int srbm_eval_trajectory(srbm_batch* h, const double* time, double* force, double* pos, int* in_contact);
+/* MPCSingleRigidBody::GetEEBoxCenter (mpc/mpc_single_rigid_body.cpp:502-509): centers[4][2] = GetCOMToHip(ee).xy */
+int srbm_get_ee_box_center(const srbm_batch* h, double* centers);
+/* MPC::GetCost (cost of prev_qp_sol, cost[batch]) and MPC::GetAvgCost (mpc/mpc.cpp:991-998: mean over all solves so far) */
+int srbm_get_cost(srbm_batch* h, double* cost);
+int srbm_get_avg_cost(srbm_batch* h, double* avg_cost);
 
 /* MPC::UpdateContactTimes (mpc/mpc.cpp:1085-1088): times[batch][4][max_contacts], counts must match the current
  * number of contact knots of every foot */
@@ -138,8 +182,13 @@ int srbm_gait_get_candidate_status(srbm_gait* g, int* status, int* err);
 /* ---- results (all copied to host) ---- */
 /* sizes[batch][8] = n, m, n_eq, n_ineq, n_force_vars, n_pos_vars, n_td_rows, n_force_samples */
 int srbm_get_sizes(srbm_batch* h, int* sizes);
-/* status[batch] = mpc::SolveQuality (mpc/include/qp/qp_interface.h:12-22); err[batch] = error bits (0 = none) */
+/* status[batch] = mpc::SolveQuality (mpc/include/qp/qp_interface.h:12-22); err[batch] = error bits (0 = none).
+ * Both describe the LAST solve only. */
 int srbm_get_status(srbm_batch* h, int* status, int* err);
+/* Sticky accumulators over every solve since creation / the last clear (multi-step launches overwrite status and err each
+ * step): acc[batch][4] = {all error bits raised, solves, solves not in {Solved, SolvedInacc}, of those MaxIter} */
+int srbm_get_status_accumulated(srbm_batch* h, int* acc);
+int srbm_clear_status_accumulators(srbm_batch* h);
 /* stats[batch][8] = alpha, cost (GetCost), L1 dynamics defect, step norm, qp iterations, res_primal, res_dual, gap_rel */
 int srbm_get_stats(srbm_batch* h, double* stats);
 /* objective of the QP at its raw minimiser, cost[batch] (the "QP Cost" column of MPC::PrintStatLineToFile, mpc/mpc.cpp:974-989) */
@@ -157,14 +206,26 @@ int srbm_get_knots(srbm_batch* h, int inst, double* times, int* kinds, int* nk, 
 /* Dense expansion of the structured QP of the LAST solve of one instance into the reference's layout
  * (rows/cols as SURVEY.md Appendix A): A[m][n], b[m], P[n][n], q[n].  Debug / parity-test aid. */
 int srbm_export_qp(srbm_batch* h, int inst, double* A, double* b, double* P, double* q);
-/* result records for collection across GPUs (one RCCL all-gather in bench.py): out_dev[batch][ld] on the handle's
- * stream = {status, n, m, cost, alpha, err, qp_iters, init_time, x[0..n)} ; ld >= 8 */
+/* result records for collection across GPUs (one RCCL all-gather in bench.py): out_dev[batch][ld] on
+ * the handle's stream.  Layout of one record (doubles), NX = 12 (N+1) + 160, NM = 12 (N+1) + 6*120 + 16 (N-3) + 16:
+ *   [0..8)  status, n, m, cost, alpha, err (sticky bits since the last clear), qp_iters, init_time
+ *   [8 .. 8+NX)           x[0..n)   primal (prev_qp_sol), zero padded
+ *   [8+NX .. 8+NX+NM)     z[0..m)   dual vector in the reference's row order, zero padded
+ *   [8+NX+NM .. +36)      contact-time counts of the 4 feet, then 4 x 8 contact times
+ * srbm_result_record_doubles(N) = 8 + NX + NM + 36.  A shorter ld truncates the record (ld >= 8). */
+int srbm_result_record_doubles(int num_nodes);
 int srbm_pack_results_dev(srbm_batch* h, double* out_dev, int ld);
+/* the same records into a HOST buffer out[batch][ld] (synchronous) */
+int srbm_pack_results(srbm_batch* h, double* out, int ld);
 /* measurement aids: HIP-event timing of the dominant kernel (srbm_k3_ipm) on the launch stream, and running totals
  * of executed IPM iterations / algorithmic flops (SURVEY.md section 8d formula) summed over the batch */
 int srbm_enable_kernel_timing(srbm_batch* h, int max_launches);
 int srbm_get_kernel_timing(srbm_batch* h, double* total_ms, int* launches);
 int srbm_get_work_counters(srbm_batch* h, double* total_ipm_iterations, double* total_algorithmic_flops);
+/* matrix-core instructions (v_mfma_f64_16x16x4_f64, 2048 flop each, counted per wave) EXECUTED by the condensing and IPM
+ * phases, summed over the batch: the executed-flop side of the roofline (the algorithmic figure counts a dense SYRK that the
+ * structured assembly never performs) */
+int srbm_get_executed_mfma(srbm_batch* h, double* total_mfma_instructions);
 /* bytes of HBM held per instance (persistent record + per-solve workspace) */
 long srbm_bytes_per_instance(void);
 

@@ -159,6 +159,7 @@ int orc_mpc_get_knots(void* p, int ee, double* times, int* ttypes, int* ftype, d
     }
     return K;
 }
+double orc_mpc_init_time(void* p) { return static_cast<OrcMPC*>(p)->mpc->InitTime(); }
 // contact times of one foot (max 32): returns count
 int orc_mpc_get_contact_times(void* p, int ee, double* times, int* types) {
     auto* h = static_cast<OrcMPC*>(p);

@@ -1,8 +1,9 @@
 """Golden vectors for Config B (BASELINE.json configs[1]): the oracle run over the first RTI steps of the loop of
 /root/reference/test/gait_opt_playground.cpp:113-126 (state := node 1 of the previous trajectory, time = i*dt) for all
-256 seeded instances.  Stores per step the solver status, the QP sizes and a checksum of the QP minimiser so that the
-GPU suite can check status classes (solved / primal infeasible) and solutions without re-running the oracle.
-Usage: python oracle/tools/make_config_b_golden.py   (writes tests/golden/config_b_rti.json)"""
+256 seeded instances.  Stores per step the solver status, the QP sizes, the Armijo step (config_b_rti.json) and the FULL QP
+minimiser of every instance and step (config_b_rti_x.npz: x[256][steps][412], zero padded beyond n) so that the GPU suite can
+check status classes (solved / primal infeasible) and solutions entry-wise without re-running the oracle.
+Usage: python oracle/tools/make_config_b_golden.py   (writes tests/golden/config_b_rti.json and config_b_rti_x.npz)"""
 import json, os, sys
 from multiprocessing import Pool
 import numpy as np
@@ -29,12 +30,15 @@ def run(b):
         out['steps'].append(dict(status=st['status'], iters=st['qp_iters'], n=sz['n'], m=sz['m'], alpha=st['alpha'],
                                  cost=st['cost'], x_sum=float(np.sum(x)), x_abs_max=float(np.abs(x).max()),
                                  x_head=[float(v) for v in x[12:24]]))
+        out.setdefault('_x', []).append(np.pad(x, (0, 412 - len(x))))
     return out
 
 
 if __name__ == '__main__':
     with Pool(8) as p:
         res = p.map(run, range(256), chunksize=4)
+    X = np.array([r.pop('_x') for r in res])
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'config_b_rti_x.npz'), x=X)
     with open(os.path.join(ROOT, 'tests', 'golden', 'config_b_rti.json'), 'w') as f:
         json.dump(dict(steps=STEPS, instances=res), f)
     from collections import Counter

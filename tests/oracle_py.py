@@ -56,7 +56,7 @@ def lib():
         L.orc_spline_create.restype = C.c_void_p
         L.orc_spline_clone.restype = C.c_void_p
         for f in ('orc_spline_value_at', 'orc_spline_end_time', 'orc_spline_start_time', 'orc_spline_partial_wrt_time',
-                  'orc_mpc_ee_value'):
+                  'orc_mpc_ee_value', 'orc_mpc_init_time'):
             getattr(L, f).restype = C.c_double
         _lib = L
     return _lib
@@ -181,6 +181,34 @@ class OracleMPC:
         return dict(K=K, times=times[:K].copy(), ttypes=tt[:K].copy(), ftype=ft.reshape(3, 64)[:, :K].copy(),
                     fvals=fv.reshape(3, 64, 2)[:, :K].copy(), ptype=pt.reshape(3, 64)[:, :K].copy(),
                     pvals=pv.reshape(3, 64, 2)[:, :K].copy())
+
+    def trajectory_record(self, host):
+        """the oracle's current mpc::Trajectory as the product's flat record (host.Trajectory = srbm_trajectory): what a caller
+        hands to MPC::SetWarmStartTrajectory.  Knot kind from (TimeType, force NodeType): LO 0, TD 1, stance-interior 2, mid-swing 3."""
+        t = host.Trajectory()
+        t.num_states = self.N + 1
+        t.init_time = self.L.orc_mpc_init_time(self.h)
+        t.node_dt = self.cfg['integrator_dt']; t.swing_height = self.cfg['swing_height']; t.foot_offset = self.cfg['foot_offset']
+        st = self.states()
+        for k in range(self.N + 1):
+            for i in range(13):
+                t.states[k][i] = st[k, i]
+        for ee in range(4):
+            kn = self.knots(ee)
+            K = kn['K']
+            assert K <= 32
+            t.nk[ee] = K
+            for k in range(K):
+                tt, ft = int(kn['ttypes'][k]), int(kn['ftype'][0][k])
+                kind = tt if tt < 2 else (2 if ft == 1 else 3)
+                t.knot_kind[ee][k] = kind
+                t.knot_time[ee][k] = kn['times'][k]
+                for c in range(3):
+                    t.force[ee][c][k][0] = kn['fvals'][c][k][0] if kind == 2 else 0.0
+                    t.force[ee][c][k][1] = kn['fvals'][c][k][1] if kind == 2 else 0.0
+                for c in range(2):
+                    t.pos_xy[ee][c][k] = kn['pvals'][c][k][0] if kind <= 1 else 0.0
+        return t
 
     def contact_times(self, ee):
         t = np.zeros(32); ty = np.zeros(32, np.int32)

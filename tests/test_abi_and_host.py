@@ -32,11 +32,10 @@ def test_library_exports_every_declared_symbol(libpath):
 
 
 def test_code_object_is_gfx950(libpath):
-    out = subprocess.run(['/opt/rocm/lib/llvm/bin/clang-offload-bundler', '--list', '--type=o', '--input=' + libpath],
-                         capture_output=True, text=True)
+    """single-target build: every offload target named in the fat binary is CDNA4 (gfx950)"""
     blob = open(libpath, 'rb').read()
-    assert b'gfx950' in blob
-    assert b'gfx90a' not in blob and b'sm_' not in blob[:0]   # single-target build
+    targets = set(re.findall(rb'amdgcn-amd-amdhsa--(gfx[0-9a-f]+)', blob))
+    assert targets == {b'gfx950'}, targets
 
 
 def test_no_gpu_fails_loudly(libpath):
@@ -75,10 +74,20 @@ def test_config_files_carry_the_reference_values():
     assert (d['num_nodes'], d['integrator_dt'], d['force_cost'], d['gait_opt_freq']) == (50, 0.02, 0.001, 5)
 
 
+def _run_two_ranks(code):
+    port = str(29500 + os.getpid() % 400)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
+
+
 def test_sharding_two_ranks_gloo():
     """bench.py shards instances over ranks with no data-path collective; results are collected with one all_gather.
     World size 2 on CPU (gloo): the shard arithmetic and the gather of result records."""
-    code = r'''
+    _run_two_ranks(r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)
 import bench
@@ -92,22 +101,53 @@ assert out.shape == (10, 4) and torch.equal(out[:, 0], torch.arange(10, dtype=to
 t = bench.max_over_ranks(float(rank + 1))
 assert t == 2.0
 dist.barrier(); dist.destroy_process_group()
-print("OK", rank)
-''' % ROOT
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29617')
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-                        '--master-port', '29617', '-c', code] if False else
-                       [sys.executable, '-c', '''
-import subprocess, sys, os
-code = %r
-procs = []
-for r in range(2):
-    env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT="29617")
-    procs.append(subprocess.Popen([sys.executable, "-c", code], env=env))
-rc = [p.wait() for p in procs]
-sys.exit(max(rc))
-''' % code], capture_output=True, text=True, timeout=300)
+''' % ROOT)
+
+
+def test_bench_gpus_flag_spawns_the_ranks():
+    """`python bench.py --gpus 2` outside torchrun must produce TWO ranks (the launcher spawns fresh processes before anything
+    touches a GPU); --dry-run walks the launcher, the sharding and the all-gather on CPU (gloo) without a HIP call."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout                     # ONE JSON line, from rank 0
+    import json
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 512 and d['config']['records_gathered'] == 512 and d['config']['gather_ok']
+    # a world size that contradicts --gpus is refused, never reported as n_gpus = 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE='1', RANK='0'), timeout=300)
+    assert r.returncode != 0 and 'refusing' in r.stderr
+
+
+def test_trajectory_record_layout_and_host_evaluation(libpath):
+    """srbm_trajectory (mpc::Trajectory as a flat record): the ctypes mirror has the library's layout, and
+    Trajectory::GetForce / GetEndEffectorLocation / GetContacts evaluate on the HOST (no GPU) with the reference's known
+    answers of test/splines_tests.cpp:58-107 (5 contact times 0, 0.2, ..., 0.8, the foot starting in swing)."""
+    L = ctypes.CDLL(libpath)
+    assert L.srbm_sizeof_trajectory() == ctypes.sizeof(host.Trajectory)
+    t = host.Trajectory()
+    t.num_states = 21; t.node_dt = 0.05; t.swing_height = 6.0; t.foot_offset = 0.0
+    # knot pattern of a swing-first foot (end_effector_splines.cpp:45-100): LO mid TD F F LO mid TD F F LO
+    times = [0.0, 0.1, 0.2, 0.2 + 0.2 / 3, 0.2 + 0.4 / 3, 0.4, 0.5, 0.6, 0.6 + 0.2 / 3, 0.6 + 0.4 / 3, 0.8]
+    kinds = [0, 3, 1, 2, 2, 0, 3, 1, 2, 2, 0]
+    for ee in range(4):
+        t.nk[ee] = len(times)
+        for k, (tt, kd) in enumerate(zip(times, kinds)):
+            t.knot_time[ee][k] = tt; t.knot_kind[ee][k] = kd
+    # position x as the reference test sets it (value = index of the mutable node, :60-62): 0 on the first lift-off knot, 2 through
+    # the first stance (TD knot 2 and its LO knot 5), 7 through the second (knots 7 and 10)
+    for k, v in zip([0, 2, 5, 7, 10], [0.0, 2.0, 2.0, 7.0, 7.0]):
+        t.pos_xy[0][0][k] = v
+    assert t.get_end_effector_location(0, 0.0)[0] == 0.0
+    assert abs(t.get_end_effector_location(0, 0.103448)[0] - 1.0517) < 1e-3       # test/splines_tests.cpp:67
+    assert abs(t.get_end_effector_location(0, 0.503448)[0] - 4.62926) < 1e-3      # :68
+    assert abs(t.get_end_effector_location(0, 0.5)[2] - 6.0) < 1e-12         # z at the mid-swing knot = swing height (:79-81)
+    assert t.get_contacts(0.3) == [True] * 4 and t.get_contacts(0.1) == [False] * 4
+    assert t.get_contact_times()[0] == [0.0, 0.2, 0.4, 0.6, 0.8]
+    with pytest.raises(RuntimeError):
+        t.get_force(0, -5.0)                   # before the first knot: the reference throws
 
 
 def test_reference_yaml_configuration_loads(tmp_path):

@@ -59,7 +59,7 @@ def test_cpp_host_side_equals_ctypes_path(tmp_path):
     ee0 = np.array([[0.2, 0.2, 0], [0.2, -0.2, 0], [-0.2, 0.2, 0], [-0.2, -0.2, 0]], float)
     g = host.BatchMPC(cfg, 2)
     g.set_state_trajectory_warm_start(s0)
-    g.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+    g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
     g.create_initial_run(s0, ee0)
     g.rti_advance(0, 4); g.synchronize()
     gait = host.BatchGaitOptimizer(g)

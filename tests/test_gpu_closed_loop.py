@@ -43,7 +43,7 @@ def test_closed_loop_rollout_matches_oracle(advance_time):
     states, ees = np.array(states), np.array(ees).reshape(B, 12)
     push_time = np.array([0.12, 0.07, 1e9])                      # instance 2 is never pushed
     impulse = np.array([[2.5, -1.0, 0.3, 0.05, -0.1, 0.2], [-1.5, 2.0, 0.0, 0.0, 0.1, -0.1], [9, 9, 9, 9, 9, 9]], float)
-    g = host.BatchMPC(cfg, B); g.set_state_trajectory_warm_start(states); g.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+    g = host.BatchMPC(cfg, B); g.set_state_trajectory_warm_start(states); g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
     g.create_initial_run(states, ees)
     g.plant_set_state(states); g.plant_set_push(push_time, impulse)
     for i in range(K):                                           # one step per call: the plant state after every step is compared

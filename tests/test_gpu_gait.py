@@ -22,7 +22,7 @@ def run_pair(cfgname, nsteps, batch=2):
     s0 = np.array(cfg['srb_init'], float)
     g = host.BatchMPC(cfg, batch)
     g.set_state_trajectory_warm_start(s0)
-    g.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+    g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
     o = OracleMPC(cfg)
     o.set_warmstart(s0)
     g.create_initial_run(s0, EE0); o.initial_run(s0, EE0)
@@ -197,7 +197,7 @@ def test_controller_loop_with_gait_step(cfgname, runs, knot_tol):
     s0 = np.array(cfg['srb_init'], float)
     g = host.BatchMPC(cfg, 2)
     g.set_state_trajectory_warm_start(s0)
-    g.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+    g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
     o = OracleMPC(cfg)
     o.set_warmstart(s0)
     g.create_initial_run(s0, EE0); o.initial_run(s0, EE0)

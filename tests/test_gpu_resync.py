@@ -1,0 +1,348 @@
+"""Full-batch, entry-wise GPU parity with the linearisation point RE-SYNCHRONISED at every step.
+
+Both sides of an SQP real-time iteration relinearise around their own previous solution, so a 1e-7 difference after one
+solve grows along the flat directions of the weakly convex QP.  Here the oracle's trajectory is
+installed on the device before every step through the reference's own entry, MPC::SetWarmStartTrajectory
+(/root/reference/mpc/mpc.cpp:110-119 = srbm_set_warm_start_trajectory), so that EVERY step of EVERY instance is a
+comparison on identical inputs: integer artefacts and knot times bit-exact, the assembled QP (A, b, P, q in the
+reference's layout) <= 1e-12 with an identical sparsity pattern, primal / dual / trajectory <= 1e-4 relative
+(BASELINE.json north_star), Armijo step equal.  The 20 steps of the Config-B protocol include windows with 148 spline
+variables and steps with touch-down position rows (n_td > 0).
+"""
+import ctypes as C
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from oracle_py import OracleMPC, load_config
+from srbm_loader import host
+from bench import config_b_instance, config_c_instance
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-4
+EE0 = np.array([[0.2, 0.2, 0], [0.2, -0.2, 0], [-0.2, 0.2, 0], [-0.2, -0.2, 0]], float)
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+def cls(v):
+    v = int(v)
+    return 'solved' if v <= 1 else ('maxiter' if v == 2 else ('infeasible' if v in (3, 5) else 'other'))
+
+
+def make_batch(cfg, states, ees):
+    B = len(states)
+    g = host.BatchMPC(cfg, B)
+    g.set_state_trajectory_warm_start(states)
+    g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
+    oracles = []
+    for b in range(B):
+        o = OracleMPC(cfg)
+        o.set_warmstart(states[b])
+        oracles.append(o)
+    return g, oracles
+
+
+def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None):
+    """cold start on both sides, then `steps` open-loop RTI steps (test/gait_opt_playground.cpp:113-126) with the device
+    re-synchronised to the oracle before every step; returns per-step statistics.  Asserts entry-wise parity."""
+    B = len(states)
+    N = cfg['num_nodes']
+    dt = cfg['integrator_dt']
+    g, oracles = make_batch(cfg, states, ees)
+    pool = pool or ThreadPoolExecutor(16)
+    list(pool.map(lambda b: oracles[b].initial_run(states[b], ees[b].reshape(4, 3)), range(B)))
+    g.create_initial_run(states, ees.reshape(B, 12))
+    # after the cold start (10 solves, each side on its own path) the two sides agree to the tolerance ...
+    xs = g.qp_solution()
+    st0, _ = g.status()
+    for b in range(B):
+        so = oracles[b].stats()['status']
+        assert cls(st0[b]) == cls(so) or {cls(st0[b]), cls(so)} <= {'solved', 'maxiter'}, (b, st0[b], so)
+    seen_sizes, seen_td, worst = set(), 0, dict(A=0.0, x=0.0, z=0.0, z_all=0.0, states=0.0, x_cert_oracle=0.0, x_cert_gpu=0.0)
+    n_cert = 0
+    n_unique = 0
+    exact_status = 0
+    total = 0
+    nx = (N + 1) * 12
+    # An instance leaves the comparison when the ORACLE's solver gives up on it (MaxIterations / numerical error: its iterate is
+    # then not a minimiser and the trajectory it continues from is solver-specific, cf. tests/test_gpu_parity.py); the device
+    # keeps running that instance on its own trajectory.
+    alive = np.ones(B, bool)
+    for i in range(steps):
+        t = i * dt
+        # ... and from here on the device starts every step from the ORACLE's trajectory
+        own = g.get_trajectory()
+        recs = (host.Trajectory * B)(*[oracles[b].trajectory_record(host) if alive[b] else own[b] for b in range(B)])
+        g.set_warm_start_trajectory(recs)
+        back = g.get_trajectory()
+        assert bytes(back) == bytes(recs)                      # the record round-trips bit for bit
+        own_states = g.trajectory_states()
+        _, own_ee, _ = g.eval_trajectory(t)
+        st_in = np.array([(o.states()[1] if i > 0 else states[b]) if alive[b] else own_states[b, 1] for b, o in enumerate(oracles)])
+        ee_in = np.array([[[o.ee_value(e, 1, c, t) for c in range(3)] for e in range(4)] if alive[b] else own_ee[b]
+                          for b, o in enumerate(oracles)]).reshape(B, 12)
+        g.get_real_time_update(st_in, t, ee_in)
+        sos = list(pool.map(lambda b: oracles[b].rti(st_in[b], t, ee_in[b].reshape(4, 3)) if alive[b] else 8, range(B)))
+        sz = g.sizes(); st, err = g.status(); stats = g.stats()
+        x = g.qp_solution(); xr = g.raw_qp_minimiser(); z, s = g.dual_solution(); tr = g.trajectory_states()
+        assert np.all(err[alive] == 0), (i, np.nonzero(err)[0][:8], err[err != 0][:8])
+        traj_after = g.get_trajectory()
+
+        def check(b):
+            o = oracles[b]
+            if not alive[b]:
+                return dict(exact=0, n=0, ntd=0, dead=1)
+            if cls(sos[b]) in ('maxiter', 'other'):
+                alive[b] = False
+                return dict(exact=0, n=0, ntd=0, dead=1)
+            osz = o.sizes()
+            n, m = osz['n'], osz['m']
+            assert (sz[b, 0], sz[b, 1], sz[b, 2], sz[b, 3], sz[b, 4], sz[b, 5], sz[b, 6]) == \
+                   (n, m, osz['n_eq'], osz['n_ineq'], osz['n_force'], osz['n_pos'], osz['n_td']), (i, b)
+            co, cg = cls(sos[b]), cls(st[b])
+            # Solved / SolvedInacc / MaxIter steer the RTI step identically (msrb.cpp:136-144); which of them an IPM reports at a
+            # 1e-15 gap tolerance is solver-internal (Clarabel is unpinned).  Infeasible must match exactly.
+            assert co == cg or {co, cg} <= {'solved', 'maxiter'}, (i, b, sos[b], st[b])
+            out = dict(exact=int(int(sos[b]) == int(st[b])), n=n, ntd=osz['n_td'])
+            # knot tables after the step (horizon shift of this step included): bit-exact
+            ta = traj_after[b]
+            for ee in range(4):
+                ko = o.knots(ee)
+                K = ko['K']
+                assert ta.nk[ee] == K, (i, b, ee)
+                assert np.array_equal(np.array(ta.knot_time[ee][:K]), ko['times']), (i, b, ee)
+            if i % qp_every == 0:
+                A, bv, P, q = g.export_qp(b)
+                Ao, bo, Po, qo = o.qp_dense()
+                # sparsity pattern: identical above rounding noise.  (The reference's SetMatrix drops EXACT zeros,
+                # sparse_matrix_builder.cpp:22-30; a spline value that is 0.0 on one side and 1e-16 on the other -- a force at
+                # a lift-off knot, evaluated with and without fused multiply-adds -- moves an entry in or out of the pattern
+                # without changing the QP; the t = 0 test of tests/test_gpu_parity.py keeps the exact-pattern check.)
+                assert np.array_equal(np.abs(A) > 1e-13, np.abs(Ao) > 1e-13), (i, b)
+                out['A'] = max(np.abs(A - Ao).max(), np.abs(bv - bo).max(), np.abs(P - Po).max(), np.abs(q - qo).max())
+                assert out['A'] <= 1e-12, (i, b, out['A'])
+            if co == 'infeasible':      # sol := prev_qp_sol (msrb.cpp:115-120): the step is zero on both sides
+                assert stats[b, 0] * stats[b, 3] == 0.0 or stats[b, 3] < 1e-12, (i, b)
+                return out
+            if co != 'solved' or cg != 'solved':
+                return out              # an unconverged QP: the iterate it stopped at is solver-specific
+            xo = o.x()
+            out['x'] = max(relerr(xr[b, :n], o.qp_x()), relerr(x[b, :n], xo))
+            assert out['x'] < REL_TOL, (i, b, out['x'])
+            out['states'] = relerr(tr[b], o.states())
+            assert out['states'] < REL_TOL, (i, b)
+            # a sample is checked against the CERTIFIED minimiser of the QP (tests/qp_polish.py: active-set polish + KKT
+            # certificate, independent of both interior-point codes): the oracle's minimiser is pinned by it, the device's too
+            if i % qp_every == 0 and (b + 5 * i) % 64 == 0:
+                from qp_polish import polish
+                is_eq = np.ones(m, bool)
+                is_eq[nx:nx + osz['n_ineq']] = False
+                xc, info = polish(Po, qo, Ao, bo, is_eq, o.qp_x(), o.z(), o.s())
+                if xc is not None:
+                    out['cert'] = 1
+                    out['x_cert_oracle'] = relerr(o.qp_x(), xc)
+                    out['x_cert_gpu'] = relerr(xr[b, :n], xc)
+                    assert out['x_cert_oracle'] < REL_TOL and out['x_cert_gpu'] < REL_TOL, (i, b, out['x_cert_oracle'], out['x_cert_gpu'])
+            # duals.  Always: the device's (x, z) is a KKT point of the ORACLE's QP (stationarity, sign, complementarity) and the
+            # dual objectives agree.  Entry-wise z == z_oracle only where the multipliers are unique, i.e. where the gradients
+            # of the active rows are linearly independent (a foot with zero force has its lower force-box row and its four
+            # pyramid rows active together: five dependent rows, any split of the multiplier is optimal).
+            if i % qp_every == 0:
+                zo, so_ = o.z(), o.s()
+                zg, sg = z[b, :m], s[b, :m]
+                xg = xr[b, :n]
+                zs = max(1.0, np.abs(zo).max())
+                assert np.abs(Po @ xg + qo + Ao.T @ zg).max() / max(1.0, np.abs(qo).max()) < 1e-7, (i, b)
+                n_eq0 = nx                               # dynamics rows first, then the inequality blocks, then TD / start rows
+                ineq = slice(nx, nx + osz['n_ineq'])
+                assert zg[ineq].min() > -1e-7 * zs and sg[ineq].min() > -1e-9, (i, b)
+                assert np.abs(zg[ineq] * sg[ineq]).max() < 1e-6 * zs, (i, b)
+                assert abs(bo @ zg - bo @ zo) <= 1e-6 * max(1.0, abs(bo @ zo)), (i, b, bo @ zg, bo @ zo)
+                active = np.ones(m, bool)
+                active[ineq] = so_[ineq] < 1e-7
+                active &= np.abs(Ao).sum(axis=1) > 0      # rows without coefficients constrain nothing
+                Aact = Ao[active]
+                out['z_all'] = np.abs(zg[active] - zo[active]).max() / zs
+                # (the rank test is the expensive part: a sample of the solves)
+                if (b + i) % 4 == 0 and np.linalg.matrix_rank(Aact, tol=1e-9) == Aact.shape[0]:
+                    out['z'] = out['z_all']
+                    out['z_unique'] = 1
+                    assert out['z'] < REL_TOL, (i, b, out['z'])
+            os_ = o.stats()
+            if os_['step_norm'] > 1e-3:           # the Armijo test is noise below that (merit differences ~1e-12)
+                assert stats[b, 0] == os_['alpha'], (i, b, stats[b, 0], os_['alpha'])
+            assert abs(stats[b, 1] - os_['cost']) <= 1e-6 * max(1.0, abs(os_['cost'])), (i, b)
+            return out
+
+        res = list(pool.map(check, range(B)))
+        for r in res:
+            if r.get('dead'):
+                continue
+            total += 1
+            exact_status += r['exact']
+            seen_sizes.add(r['n']); seen_td += r['ntd'] > 0
+            n_unique += r.get('z_unique', 0)
+            n_cert += r.get('cert', 0)
+            for k in worst:
+                if k in r:
+                    worst[k] = max(worst[k], r[k])
+        # foot-box size (info_.ee_box_size, grown / shrunk by the status of each solve): same on both sides
+        for b in (0, B // 2, B - 1):
+            if alive[b]:
+                assert np.array_equal(g.knots(b)['box'], np.array(oracles[b].stats()['box'])), (i, b)
+    assert alive.sum() >= 0.97 * B, alive.sum()
+    return dict(alive=int(alive.sum()), sizes=seen_sizes, td_steps=seen_td, worst=worst, exact_status=exact_status, total=total, z_unique=n_unique, certified=n_cert)
+
+
+def test_config_b_all_256_instances_entrywise_over_20_steps():
+    cfg = load_config()
+    B = 256
+    states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees)
+    r = resync_protocol(cfg, states, ees, steps=20)
+    nx = 21 * 12
+    assert {nx + 120, nx + 148} <= r['sizes'], r['sizes']         # both window sizes were compared
+    assert r['td_steps'] > 0                                      # ... and steps with touch-down position rows
+    assert r['worst']['A'] <= 1e-12 and r['worst']['x'] < REL_TOL and r['worst']['z'] < REL_TOL
+    print('resync parity, 256 x 20: alive', r['alive'], 'worst', r['worst'], 'exact status matches %d / %d' % (r['exact_status'], r['total']),
+          'duals compared entry-wise (unique multipliers) in %d solves' % r['z_unique'], 'certified minimisers: %d' % r['certified'])
+    assert r['certified'] >= 40
+
+
+def test_config_c_values_at_n20_entrywise():
+    """BASELINE config 3 as written: a1_gait_opt_config.yaml values (mu 0.6, force bound 200, Q, swing 0.1, target x = y = 1) at
+    N = 20, dt = 0.05 -- the RTI path of that configuration, 64 instances x 12 steps, entry-wise as above"""
+    cfg = load_config('a1_gait_opt_config', num_nodes=20, integrator_dt=0.05)
+    B = 64
+    states, ees = zip(*[config_c_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees)
+    r = resync_protocol(cfg, states, ees, steps=12, qp_every=2)
+    assert r['worst']['A'] <= 1e-12 and r['worst']['x'] < REL_TOL
+    print('resync parity, config C values 64 x 12: worst', r['worst'])
+
+
+def test_trajectory_roundtrip_clone_and_evaluation():
+    """GetTrajectory / SetWarmStartTrajectory / copy semantics / spline evaluation entries of the boundary"""
+    cfg = load_config()
+    B = 4
+    states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees).reshape(B, 12)
+    g, oracles = make_batch(cfg, states, ees)
+    g.create_initial_run(states, ees)
+    for b in range(B):
+        oracles[b].initial_run(states[b], ees[b].reshape(4, 3))
+    g.rti_advance(0, 3); g.synchronize()
+    # value semantics: a clone continues exactly like the original, and is independent of it
+    c = g.clone()
+    g.rti_advance(3, 2); c.rti_advance(3, 2); g.synchronize(); c.synchronize()
+    assert np.array_equal(g.qp_solution(), c.qp_solution()) and bytes(g.get_trajectory()) == bytes(c.get_trajectory())
+    c.rti_advance(5, 1); c.synchronize()
+    assert not np.array_equal(g.qp_solution(), c.qp_solution())
+    # SetWarmStartTrajectory(GetTrajectory()) of another object: the next solve is bit-identical
+    d = host.BatchMPC(cfg, B)
+    d.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
+    d.set_warm_start_trajectory(g.get_trajectory())
+    tr = g.trajectory_states()
+    t5 = 5 * cfg['integrator_dt']
+    f, p, cont = g.eval_trajectory(t5)
+    g.get_real_time_update(tr[:, 1], t5, p.reshape(B, 12))
+    d.get_real_time_update(tr[:, 1], t5, p.reshape(B, 12))
+    assert np.array_equal(g.qp_solution(), d.qp_solution())
+    assert np.array_equal(g.sizes(), d.sizes())
+    # device evaluation == host evaluation of the record == oracle spline on the oracle's own trajectory
+    recs = g.get_trajectory()
+    t = recs[0].init_time + 0.123
+    f, p, cont = g.eval_trajectory(t)
+    for b in range(B):
+        for ee in range(4):
+            # (same source on both sides; the device build contracts a*b + c into fused multiply-adds, x86-64 does not)
+            assert np.allclose(recs[b].get_force(ee, t), f[b, ee], rtol=1e-12, atol=1e-12)
+            assert np.allclose(recs[b].get_end_effector_location(ee, t), p[b, ee], rtol=1e-13, atol=1e-14)
+            assert recs[b].get_contacts(t)[ee] == bool(cont[b, ee])
+    o = oracles[0]
+    rec_o = o.trajectory_record(host)
+    for ee in range(4):
+        for tt in (0.0, 0.07, 0.31, 0.77):
+            assert np.allclose(rec_o.get_force(ee, tt), [o.ee_value(ee, 0, c_, tt) for c_ in range(3)], rtol=1e-12, atol=1e-12)
+            assert np.allclose(rec_o.get_end_effector_location(ee, tt), [o.ee_value(ee, 1, c_, tt) for c_ in range(3)], rtol=1e-13, atol=1e-14)
+    # a malformed record is refused
+    bad = g.get_trajectory()
+    bad[1].nk[2] = 1
+    with pytest.raises(RuntimeError):
+        g.set_warm_start_trajectory(bad)
+    # GetEEBoxCenter = GetCOMToHip(ee).xy (SURVEY.md 8d constants), GetCost / GetAvgCost
+    assert np.allclose(g.ee_box_center(), [[0.2055, 0.147], [0.2055, -0.147], [-0.1555, 0.147], [-0.1555, -0.147]], atol=1e-12)
+    assert np.array_equal(g.cost(), g.stats()[:, 1])
+    h = host.BatchMPC(cfg, 1)
+    h.set_state_trajectory_warm_start(states[0]); h.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
+    costs = []
+    for k in range(4):
+        h.get_real_time_update(states[0], 0.0, ees[0])
+        costs.append(h.cost()[0])
+    assert abs(h.avg_cost()[0] - np.mean(costs)) <= 1e-12 * abs(np.mean(costs))
+
+
+def test_sticky_error_accumulators_survive_multi_step_launches():
+    """kernel 1 restarts err / status at every solve, so a K-step launch used to certify only its last step.
+    The accumulators keep every bit and count the solves by outcome."""
+    cfg = load_config()
+    B = 8
+    states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees).reshape(B, 12)
+    g = host.BatchMPC(cfg, B)
+    g.set_state_trajectory_warm_start(states)
+    g.create_initial_run(states, ees)
+    g.clear_status_accumulators()
+    g.rti_advance(0, 6); g.synchronize()
+    acc = g.status_accumulated()
+    assert np.all(acc[:, 0] == 0) and np.all(acc[:, 1] == 6) and np.all(acc[:, 2] == 0)
+    # an error raised BEFORE a solve (a lookup outside the knot range: the reference throws) is still visible after later solves
+    f, p, c = g.eval_trajectory(np.full(B, -50.0))
+    _, err = g.status()
+    assert np.all(err & 1)                                   # SRBM_ERR_TIME_SMALL
+    g.rti_advance(6, 2); g.synchronize()
+    _, err = g.status()
+    acc = g.status_accumulated()
+    assert np.all(err == 0) and np.all(acc[:, 0] & 1) and np.all(acc[:, 1] == 8)
+    g.clear_status_accumulators(); g.synchronize()
+    assert np.all(g.status_accumulated() == 0)
+    # a failed solve in the MIDDLE of a launch: an iteration limit of 3 makes every solve MaxIter; restore, run on
+    g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 3)
+    g.rti_advance(8, 2); g.synchronize()
+    g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
+    g.rti_advance(10, 3); g.synchronize()
+    acc = g.status_accumulated()
+    assert np.all(acc[:, 1] == 5) and np.all(acc[:, 2] >= 2) and np.all(acc[:, 3] >= 2)
+
+
+def test_result_record_carries_primal_dual_and_contact_times():
+    """SURVEY.md 8e record: {status, n, m, cost, alpha, err, iters, t, x[n], z[m], contact times} packed on the device"""
+    cfg = load_config()
+    B = 4
+    states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees).reshape(B, 12)
+    g = host.BatchMPC(cfg, B)
+    g.set_state_trajectory_warm_start(states)
+    g.create_initial_run(states, ees)
+    g.rti_advance(0, 4); g.synchronize()
+    LD = g.result_record_doubles()
+    N = cfg['num_nodes']
+    NX, NM = 12 * (N + 1) + 160, 12 * (N + 1) + 720 + 16 * (N - 3) + 16
+    assert LD == 8 + NX + NM + 36
+    r = g.pack_results()
+    sz = g.sizes(); st, _ = g.status(); x = g.qp_solution(); z, _ = g.dual_solution(); stats = g.stats()
+    trajs = g.get_trajectory()
+    for b in range(B):
+        n, m = int(sz[b, 0]), int(sz[b, 1])
+        assert (r[b, 0], r[b, 1], r[b, 2]) == (st[b], n, m) and r[b, 3] == stats[b, 1] and r[b, 4] == stats[b, 0]
+        assert np.array_equal(r[b, 8:8 + n], x[b, :n]) and np.all(r[b, 8 + n:8 + NX] == 0)
+        assert np.array_equal(r[b, 8 + NX:8 + NX + m], z[b, :m]) and np.all(r[b, 8 + NX + m:8 + NX + NM] == 0)
+        ct = trajs[b].get_contact_times()
+        oc = 8 + NX + NM
+        for ee in range(4):
+            assert r[b, oc + ee] == len(ct[ee])
+            assert np.array_equal(r[b, oc + 4 + 8 * ee: oc + 4 + 8 * ee + len(ct[ee])], ct[ee])

@@ -142,6 +142,8 @@ def test_config_b_fixture_is_reproducible_from_the_oracle():
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle', 'tools'))
     import make_config_b_golden as mk
     gold = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'config_b_rti.json')))
+    X = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'config_b_rti_x.npz'))['x']
+    assert X.shape == (256, gold['steps'], 412)
     statuses = [r['steps'][0]['status'] for r in gold['instances']]
     assert len(statuses) == 256 and statuses.count(3) >= 4
     for b in (0, 11, statuses.index(3), 255):
@@ -150,6 +152,7 @@ def test_config_b_fixture_is_reproducible_from_the_oracle():
         for a, r in zip(got['steps'], ref['steps']):
             assert (a['status'], a['iters'], a['n'], a['m'], a['alpha']) == (r['status'], r['iters'], r['n'], r['m'], r['alpha'])
             assert abs(a['x_sum'] - r['x_sum']) <= 1e-9 * max(1.0, abs(r['x_sum']))
+        assert np.array_equal(np.array(got['_x']), X[b])           # the full minimisers, bit for bit
 
 
 def test_plant_integral_restates_the_euler_integrator():
