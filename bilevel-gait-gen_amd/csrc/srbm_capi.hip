@@ -442,7 +442,7 @@ int srbm_batch_create(srbm_batch** out, int batch, const srbm_mpc_info* info, co
     // ClarabelInterface::ConfigureForInitialRun / ConfigureForRealTime (clarabel_interface.cpp:165-175) run every solve of the
     // reference at tol_gap 1e-15, tol_feas 1e-10: the defaults here.  The gap of this QP stops improving around 1e-14..1e-15
     // in fp64 (the loop then ends on its progress test), but WHERE it stops decides how well the minimiser is determined along
-    // the flat directions of the weakly convex QP: measured against the oracle on identical QPs (scripts/dev_accuracy.py,
+    // the flat directions of the weakly convex QP: measured against the CPU restatement of the reference on identical QPs (scripts/dev_accuracy.py,
     // 1024 solves) the worst relative primal error is 1.3e-4 at 1e-13, 5e-5 at 1e-14 and 1.4e-5 at 1e-15, for 17.3 / 18.0 /
     // 18.9 IPM iterations per solve.  The parity tolerance of the path is 1e-4.  srbm_set_solver_tolerances overrides.
     p.tol_gap_abs = 1e-15; p.tol_gap_rel = 1e-15; p.tol_feas = 1e-10;
