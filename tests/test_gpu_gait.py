@@ -16,13 +16,13 @@ def relerr(a, b):
     return np.abs(a - b).max() / max(1.0, np.abs(b).max())
 
 
-def run_pair(cfgname, nsteps, batch=2):
+def run_pair(cfgname, nsteps, batch=2, tol=1e-15):
     """GPU batch + oracle brought to the same point of an open-loop RTI run (test/gait_opt_playground.cpp:113-126)"""
     cfg = load_config(cfgname)
     s0 = np.array(cfg['srb_init'], float)
     g = host.BatchMPC(cfg, batch)
     g.set_state_trajectory_warm_start(s0)
-    g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
+    g.set_solver_tolerances(tol, tol, 1e-10, 200)
     o = OracleMPC(cfg)
     o.set_warmstart(s0)
     g.create_initial_run(s0, EE0); o.initial_run(s0, EE0)
@@ -32,6 +32,9 @@ def run_pair(cfgname, nsteps, batch=2):
         t = i * dt
         state = o.states()[1]
         ee = np.array([[o.ee_value(e, 1, c, t) for c in range(3)] for e in range(4)])
+        # both sides linearise at the SAME point (MPC::SetWarmStartTrajectory with the oracle's trajectory, cf. tests/test_gpu_resync.py):
+        # what is compared below is then the bilevel step on identical QPs, not the drift of two SQP paths
+        g.set_warm_start_trajectory([o.trajectory_record(host)] * batch)
         o.rti(state, t, ee)
         g.get_real_time_update(state, t, ee)
     return cfg, g, o, state, ee, t
@@ -134,16 +137,26 @@ def test_kkt_sensitivity(cfgname, nsteps):
     assert np.abs(Ae @ dz).max() <= 1e-9
     # (2) oracle: dq = dz + x*, dh = -lam o dlam, db = -dnu (the QP partials the gradient is built from)
     xo = o.x(); lam_o = o.z()[nx:nx + mi]
-    assert relerr(dz + xg, do[:n] + xo) < REL_TOL
-    assert np.abs(mu_g - lam_o * do[n:n + mi])[live].max() <= 2e-3 * max(1.0, np.abs(lam_o).max())
-    assert np.abs(dn - do[n + mi:]).max() <= 2e-3 * max(1.0, np.abs(do[n + mi:]).max())
+    s_o = o.s()[nx:nx + mi]
+    e_dq = relerr(dz + xg, do[:n] + xo)
+    dmu = np.abs(mu_g - lam_o * do[n:n + mi]) / max(1.0, np.abs(lam_o).max())
+    e_dn = np.abs(dn - do[n + mi:]).max() / max(1.0, np.abs(do[n + mi:]).max())
+    # degenerate rows: multiplier AND slack both tiny (lambda_i ~ s_i ~ sqrt(mu)); lambda_i dlambda_i = -lambda_i (G dz)_i / s_i is then a
+    # ratio of two rounding-level numbers, a property of where each interior-point path stopped, not of the QP
+    thr = 1e-5 * max(1.0, np.abs(lam_o).max())
+    degenerate = (lam_o < thr) & (s_o < thr)
+    # (with both sides on the same QP and the reference's 1e-15 gap tolerance even those rows agree: asserted for ALL live rows)
+    print('sensitivity vs oracle [%s, %d]: dq %.1e  dh (non-degenerate rows) %.1e  dh (degenerate rows: %d) %.1e  db %.1e' %
+          (cfgname, nsteps, e_dq, dmu[live & ~degenerate].max(), (live & degenerate).sum(), dmu[live & degenerate].max() if (live & degenerate).any() else 0.0, e_dn))
+    assert e_dq < REL_TOL
+    assert dmu[live].max() < REL_TOL
+    assert e_dn < REL_TOL
 
 
 @pytest.mark.parametrize('cfgname,nsteps', [('a1_configuration', 3), ('a1_configuration', 8), ('a1_configuration', 13),
                                             ('a1_gait_opt_config', 2), ('a1_config_distr_rejection', 4)])
 def test_cost_gradient_wrt_contact_times_matches_oracle(cfgname, nsteps):
-    """a13 + a14: dH/dtheta for every contact time.  Tolerance 1e-3 of the largest entry: the terms carried by dz and
-    dlam are solver-path dependent on degenerate rows (see test_kkt_sensitivity); the envelope part dominates."""
+    """a13 + a14: dH/dtheta for every contact time, 1e-4 of the largest entry (both sides on the same QP)."""
     cfg, g, o, state, ee, t = run_pair(cfgname, nsteps)
     assert o.stats()['status'] == 0 and g.status()[0][0] == 0
     go = o.gait_gradient()
@@ -156,7 +169,38 @@ def test_cost_gradient_wrt_contact_times_matches_oracle(cfgname, nsteps):
     assert valid[0] == 1 and counts[0].sum() == nv
     assert np.array_equal(gg[0], gg[1])
     assert np.all(gg[0, nv:] == 0)
-    assert np.abs(gg[0, :nv] - go).max() <= 1e-3 * max(1.0, np.abs(go).max()), (gg[0, :nv], go)
+    e = np.abs(gg[0, :nv] - go).max() / max(1.0, np.abs(go).max())
+    print('dH/dtheta vs oracle [%s, %d]: %.1e of the largest entry (%.3g)' % (cfgname, nsteps, e, np.abs(go).max()))
+    assert e < REL_TOL, (gg[0, :nv], go)
+
+
+def test_gradient_entries_that_depend_on_the_interior_point_path():
+    """The as-coded sensitivity system (+diag(s), clarabel_interface.cpp:268,355) divides by the slack of every inequality row:
+    on rows where multiplier and slack both vanish the quotient is decided by WHERE an interior-point path stops, for any
+    solver (Clarabel, the oracle's restatement, this one).  At run 4 of the N = 50 gait configuration four of the twenty
+    entries of dH/dtheta are of that kind (the oracle returns +-1.16e5 there, the device +-1.3e2).  They are identified by
+    the device's own evidence -- the gradient of the same QP solved to a 1e-13 and to a 1e-15 gap -- and masked explicitly;
+    every other entry must match the oracle to 1e-4."""
+    cfg, g, o, state, ee, t = run_pair('a1_gait_opt_config', 5)
+    go = o.gait_gradient()
+    assert go is not None
+    nv = len(go)
+    grads = []
+    for tol in (1e-15, 1e-13):
+        # the same QPs again (every step re-synchronised to the oracle's trajectory), solved to this gap tolerance
+        cfg2, g2, o2, _, _, _ = run_pair('a1_gait_opt_config', 5, tol=tol)
+        gait = host.BatchGaitOptimizer(g2)
+        gait.compute_gradient()
+        gg, valid = gait.gradient()
+        assert valid[0] == 1
+        grads.append(gg[0, :nv].copy())
+    scale = max(1.0, np.abs(grads[0]).max())
+    path_dependent = np.abs(grads[0] - grads[1]) > 1e-3 * scale
+    e = np.abs(grads[0] - go) / max(1.0, np.abs(go[~path_dependent]).max())
+    print('dH/dtheta [a1_gait_opt_config, run 4]: %d path-dependent entries %s masked, the other %d agree to %.1e' %
+          (path_dependent.sum(), np.nonzero(path_dependent)[0], (~path_dependent).sum(), e[~path_dependent].max()))
+    assert 0 < path_dependent.sum() <= 6
+    assert e[~path_dependent].max() < REL_TOL
 
 
 @pytest.mark.parametrize('cfgname,nsteps', [('a1_configuration', 3), ('a1_configuration', 8), ('a1_gait_opt_config', 2),
@@ -179,19 +223,26 @@ def test_contact_time_lp_matches_oracle(cfgname, nsteps):
     assert np.all(st == 0)
     assert np.all(np.abs(step[0, :nv]) <= 1 + 1e-8) and np.all(step[0, nv:] == 0)
     val_g, val_o = gg[0, :nv] @ step[0, :nv], go @ step_o[:nv]
-    assert abs(val_g - val_o) <= 2e-3 * max(1.0, abs(val_o))
+    print('LP value [%s, %d]: device %.9g oracle %.9g' % (cfgname, nsteps, val_g, val_o))
+    assert abs(val_g - val_o) <= REL_TOL * max(1.0, abs(val_o))
     assert abs(pred[0] + val_g) <= 1e-9 * max(1.0, abs(val_g))
     big = np.abs(go) > 1e-3 * np.abs(go).max()
     assert np.abs(step[0, :nv] - step_o[:nv])[big].max() <= 1e-4
 
 
-@pytest.mark.parametrize('cfgname,runs,knot_tol', [('a1_gait_opt_config', 12, 1e-9), ('a1_configuration', 7, 1e-2)])
-def test_controller_loop_with_gait_step(cfgname, runs, knot_tol):
+@pytest.mark.parametrize('cfgname,runs,knot_tol,resync', [('a1_gait_opt_config', 12, 1e-9, False), ('a1_configuration', 7, 1e-2, False),
+                                                          ('a1_gait_opt_config', 12, 0.0, True), ('a1_configuration', 12, 0.0, True)])
+def test_controller_loop_with_gait_step(cfgname, runs, knot_tol, resync):
     """The controller's MPC loop with the bilevel step every 5th iteration (controllers/mpc_controller.cpp:320-346),
-    device-resident (srbm_gait_rti_advance) against the same protocol on the oracle.  For a1_configuration the run
-    stops after the first line search: a contact time beyond the horizon has a zero gradient, the LP leaves its step
-    undetermined (the two LP codes return 0.935 and 0.928), and once that knot enters the horizon the two runs are two
-    equally valid different gait schedules; until then its only trace is in the knot table (knot_tol)."""
+    device-resident (srbm_gait_rti_advance) against the same protocol on the oracle.
+    resync = False: each side on its own path.  For a1_configuration the run stops after the first line search: a contact
+    time beyond the horizon has a zero gradient, the LP leaves its step undetermined (the two LP codes return 0.935 and
+    0.928 -- OSQP in the reference would return a third value), and once that knot enters the horizon the two runs are two
+    equally valid different gait schedules; until then its only trace is in the knot table (knot_tol).
+    resync = True: every step starts from the oracle's trajectory (MPC::SetWarmStartTrajectory) and the line search uses
+    the oracle's LP step (the LP itself is compared in test_contact_time_lp_matches_oracle): the protocol, the candidate
+    schedules and the installed winner are then compared on identical inputs -- knot tables BIT-EXACT, through two line
+    searches."""
     F = 5
     cfg = load_config(cfgname)
     s0 = np.array(cfg['srb_init'], float)
@@ -209,16 +260,22 @@ def test_controller_loop_with_gait_step(cfgname, runs, knot_tol):
         t = run * dt
         state = o.states()[1]
         ee = np.array([[o.ee_value(e, 1, c, t) for c in range(3)] for e in range(4)])
+        if resync:
+            g.set_warm_start_trajectory([o.trajectory_record(host)] * 2)
+        step_o = None
         if run % F == 0 and run > 0 and ready:
-            o.gait_line_search(state, t, ee); ready = False; n_ls += 1
+            k_o, costs_o = o.gait_line_search(state, t, ee); ready = False; n_ls += 1
         elif (run + 1) % F == 0 and run > 0:
             o.rti(state, t, ee)
             ready = o.gait_gradient() is not None
             if ready:
-                o.gait_optimize(t)
+                step_o, _ = o.gait_optimize(t)
         else:
             o.rti(state, t, ee); ready = False
         gait.rti_advance(run, 1, F); g.synchronize()
+        if resync and step_o is not None:
+            nv = int(gait.contact_times()[1][0].sum())
+            gait.set_step(step_o[:nv])
         st, err = g.status()
         assert np.all(err == 0)
         tr = g.trajectory_states()
@@ -228,4 +285,4 @@ def test_controller_loop_with_gait_step(cfgname, runs, knot_tol):
         for e in range(4):
             ko = o.knots(e)
             assert kg['nk'][e] == ko['K'] and np.abs(kg['times'][e, :ko['K']] - ko['times']).max() <= knot_tol, (run, e)
-    assert n_ls >= 1
+    assert n_ls >= (2 if resync else 1)
