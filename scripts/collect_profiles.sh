@@ -1,17 +1,28 @@
 #!/bin/bash
 # Round profiles of bench.py on the GPU box (run through gpurun from the repo root):
-#   bash scripts/collect_profiles.sh r01
-# Three rocprofv3 runs of the same command -- kernel trace + stats, then the two PMC passes on their own (the guide's
-# HBM recipe: FETCH_SIZE and WRITE_SIZE in separate passes, no other tracing) -- plus one unprofiled run.  Raw output goes
-# to gpurun_out/prof/, the summaries judged are written by scripts/summarize_pmc.py into profiles/<round>/ afterwards.
-set -e -o pipefail
-ROUND=${1:-r01}
+#   bash scripts/collect_profiles.sh
+# One unprofiled run, then rocprofv3 runs of the same command: kernel trace + stats, and the PMC passes each ON ITS OWN (the
+# guide's recipe: FETCH_SIZE and WRITE_SIZE cannot share a pass; no tracing beside --pmc; the program itself directly after `--`):
+#   pmc_fetch  FETCH_SIZE                      pmc_write  WRITE_SIZE
+#   pmc_sq1    SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
+#   pmc_sq2    SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_LDS SQ_WAIT_INST_LDS
+# Raw output goes to gpurun_out/prof/, the summaries judged are written by scripts/summarize_pmc.py into profiles/<round>/.
+set -o pipefail
 OUT=gpurun_out/prof
+rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
 CMD="bench.py --no-cpu-baseline --gait-steps 0 --closed-loop-steps 0"
-python3 $CMD > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc --output-format csv -- python3 $CMD > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc --output-format csv -- python3 $CMD > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.err
-find $OUT -name "*.csv" | head -20
+python3 $CMD > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err || exit 1
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || exit 1
+pass() {   # name, counters...
+    local name=$1; shift
+    rocprofv3 --pmc "$@" -d $OUT/$name -o pmc --output-format csv -- python3 $CMD > $OUT/bench_$name.json 2> $OUT/$name.err
+    echo "$name rc=$?" >> $OUT/passes.log
+}
+pass pmc_fetch FETCH_SIZE
+pass pmc_write WRITE_SIZE
+pass pmc_sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
+pass pmc_sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU
+cat $OUT/passes.log
+find $OUT -name "*.csv" | sort

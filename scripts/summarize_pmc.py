@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
 """profiles/<round>/ from the raw rocprofv3 output of scripts/collect_profiles.sh (gpurun_out/prof/):
-   python scripts/summarize_pmc.py r01
-Writes bench_kernel_stats.csv (the --stats kernel summary), k3_timed_region.txt (duration of the timed-region launch of the
-dominant kernel from the kernel trace), bench_*.json (the bench lines of the runs) and k3_pmc_traffic.json (the two PMC
-passes, per launch of the timed region, with the gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md)."""
+   python scripts/summarize_pmc.py r02
+Writes bench_kernel_stats.csv (the --stats kernel summary), timed_region.txt (durations of the timed-region launches of the
+dominant kernel from the kernel trace, beside the live HIP-event figure of the same run), bench_*.json (the bench lines of the
+runs) and pmc_summary.json: every PMC pass per launch of the timed region -- HBM traffic with the gfx950 corrections of
+/opt/skills/guides/MI355X_MICROARCH.md, matrix-pipe busy fraction, LDS bank conflicts, wave occupancy -- stamped with the
+sha of the kernel sources it was measured on (bench.py quotes it only for those sources)."""
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+sys.path.insert(0, ROOT)
+import bench
+rnd = sys.argv[1] if len(sys.argv) > 1 else bench.PROFILE_ROUND
 src = os.path.join(ROOT, 'gpurun_out', 'prof')
 dst = os.path.join(ROOT, 'profiles', rnd)
 os.makedirs(dst, exist_ok=True)
@@ -15,46 +19,77 @@ KERNEL = 'srbm_rti_fused'
 
 def find(sub, pat):
     hits = sorted(glob.glob(os.path.join(src, sub, '**', pat), recursive=True))
-    if not hits:
-        raise SystemExit('missing %s/%s' % (sub, pat))
-    return hits[0]
+    return hits[0] if hits else None
+
+
+def bench_line(name):
+    try:
+        return json.loads(open(os.path.join(src, name)).read().strip().splitlines()[-1])
+    except Exception:
+        return None
 
 
 shutil.copy(find('trace', '*kernel_stats.csv'), os.path.join(dst, 'bench_kernel_stats.csv'))
 for name in ('bench_unprofiled.json', 'bench_under_rocprof.json'):
     shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+ub, pb = bench_line('bench_unprofiled.json'), bench_line('bench_under_rocprof.json')
+steps, repeats = pb['steps'], pb['repeats']
 rows = [r for r in csv.DictReader(open(find('trace', '*kernel_trace.csv'))) if KERNEL in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-last = rows[-1]
-ms = (int(last['End_Timestamp']) - int(last['Start_Timestamp'])) / 1e6
-bench = json.loads(open(os.path.join(src, 'bench_under_rocprof.json')).read().strip().splitlines()[-1])
-steps = bench['steps']
-open(os.path.join(dst, 'k3_timed_region.txt'), 'w').write(
-    '%s: %d launches (warm-up, timed region of %d steps); timed-region launch: %.3f ms = %.3f ms per RTI step; '
-    'live HIP-event figure of the same run: %.3f ms\n' % (KERNEL, len(rows), steps, ms, ms / steps, bench['roofline']['avg_launch_ms']))
+timed = rows[-repeats:]
+ms = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in timed]
+with open(os.path.join(dst, 'timed_region.txt'), 'w') as f:
+    f.write('%s: %d launches in the trace (1 warm-up launch of %d steps + %d timed regions of %d steps)\n' % (KERNEL, len(rows), pb['warmup'], repeats, steps))
+    f.write('timed-region launches, kernel trace:  %s ms   mean %.3f ms = %.4f ms per RTI step\n' % (' '.join('%.3f' % v for v in ms), sum(ms) / len(ms), sum(ms) / len(ms) / steps))
+    f.write('live HIP-event figure of the same run (bench.py roofline.avg_launch_ms): %.3f ms\n' % pb['roofline']['avg_launch_ms'])
+    f.write('unprofiled run: avg_launch_ms %.3f, ms_per_step %.4f, value %.0f it/s\n' % (ub['roofline']['avg_launch_ms'], ub['ms_per_step'], ub['value']))
 
 
-def counter(sub, cname):
-    tot = {}
-    for r in csv.DictReader(open(find(sub, '*counter_collection.csv'))):
-        if KERNEL in r['Kernel_Name'] and r['Counter_Name'] == cname:
-            tot.setdefault(r['Dispatch_Id'], 0.0)
-            tot[r['Dispatch_Id']] += float(r['Counter_Value'])
-    ids = sorted(tot, key=int)
-    return tot[ids[-1]], len(ids)          # the last dispatch is the timed region
+def counters(sub):
+    """per counter: mean over the timed-region dispatches of the kernel (sum over the agents / XCDs / SEs as rocprofv3 reports them)"""
+    path = find(sub, '*counter_collection.csv')
+    if not path:
+        return {}
+    per = {}
+    for r in csv.DictReader(open(path)):
+        if KERNEL in r['Kernel_Name']:
+            d = per.setdefault(r['Counter_Name'], {})
+            d[int(r['Dispatch_Id'])] = d.get(int(r['Dispatch_Id']), 0.0) + float(r['Counter_Value'])
+    out = {}
+    for c, d in per.items():
+        ids = sorted(d)[-repeats:]
+        out[c] = sum(d[i] for i in ids) / len(ids)
+    return out
 
 
-fetch_kb, nl = counter('pmc_fetch', 'FETCH_SIZE')
-write_kb, _ = counter('pmc_write', 'WRITE_SIZE')
-hbm = (2.0 * fetch_kb + write_kb) * 1024.0
-json.dump({
-    'kernel': KERNEL, 'steps_per_launch': steps, 'launches_seen': nl,
-    'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two separate passes, no other tracing) -- python3 bench.py --no-cpu-baseline --gait-steps 0 --closed-loop-steps 0',
-    'FETCH_SIZE_KB_per_launch': fetch_kb, 'WRITE_SIZE_KB_per_launch': write_kb,
-    'correction': 'gfx950: FETCH_SIZE counts 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM section; calibrated there for '
-                  '16 B/lane streaming reads, this kernel reads 8 B/lane: upper bound); WRITE_SIZE as reported',
-    'hbm_bytes_per_launch': hbm, 'hbm_bytes_per_rti_step': hbm / steps,
-    'note': 'counters sit on the memory side of L2 and include Infinity-Cache hits',
-}, open(os.path.join(dst, 'k3_pmc_traffic.json'), 'w'), indent=1)
-print(open(os.path.join(dst, 'k3_timed_region.txt')).read())
-print('FETCH %.1f MB/step  WRITE %.1f MB/step  corrected HBM %.1f MB/step' % (fetch_kb / 1024 / steps, write_kb / 1024 / steps, hbm / 1e6 / steps))
+F, W, S1, S2 = counters('pmc_fetch'), counters('pmc_write'), counters('pmc_sq1'), counters('pmc_sq2')
+summ = {'kernel': KERNEL, 'round': rnd, 'kernel_source_sha': bench.kernel_source_sha(), 'steps_per_launch': steps, 'timed_launches': repeats,
+        'command': 'rocprofv3 --pmc <one pass per counter group, no other tracing> -- python3 bench.py --no-cpu-baseline --gait-steps 0 --closed-loop-steps 0',
+        'kernel_trace_ms_per_launch': sum(ms) / len(ms), 'hip_event_ms_per_launch_same_run': pb['roofline']['avg_launch_ms'],
+        'raw_counters_per_launch': {**F, **W, **S1, **S2}}
+if 'FETCH_SIZE' in F and 'WRITE_SIZE' in W:
+    hbm = (2.0 * F['FETCH_SIZE'] + W['WRITE_SIZE']) * 1024.0
+    summ.update({'FETCH_SIZE_KB_per_launch': F['FETCH_SIZE'], 'WRITE_SIZE_KB_per_launch': W['WRITE_SIZE'],
+                 'hbm_correction': 'gfx950: FETCH_SIZE counts 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM section; calibrated there for 16 B/lane '
+                                   'streaming reads, this kernel reads 8 B/lane: an upper bound); WRITE_SIZE as reported; both sit on the memory side of L2 and '
+                                   'include Infinity-Cache hits',
+                 'hbm_bytes_per_launch': hbm, 'hbm_bytes_per_step': hbm / steps,
+                 'algorithmic_bytes_per_step': 256 * 12.8e3, 'traffic_over_algorithmic': hbm / steps / (256 * 12.8e3)})
+if 'SQ_WAVE_CYCLES' in S1:
+    # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES and SQ_BUSY_CYCLES count
+    # cycles (guide, 's_memtime tick vs SQ PMC units'); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    gui = S1.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
+    summ.update({'gpu_cycles_per_launch': gui,
+                 'effective_clock_GHz': gui / (sum(ms) / len(ms) * 1e6) if gui else None,
+                 'mfma_busy_cycles_per_launch': S1.get('SQ_VALU_MFMA_BUSY_CYCLES'),
+                 # 256 CUs x 4 SIMDs each could be busy for every GPU cycle of the launch
+                 'mfma_busy_frac': S1.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui * 256 * 4) if gui else None,
+                 'occupancy_waves_per_cu': 4.0 * S1['SQ_WAVE_CYCLES'] / (gui * 256) if gui else None,
+                 'wave_cycles_split': {k: S1[k] / S1['SQ_WAVE_CYCLES'] for k in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY') if k in S1}})
+if 'SQ_LDS_BANK_CONFLICT' in S2:
+    summ.update({'lds_bank_conflict_frac': S2['SQ_LDS_BANK_CONFLICT'] / S2['SQ_LDS_IDX_ACTIVE'] if S2.get('SQ_LDS_IDX_ACTIVE') else None,
+                 'lds_active_frac_of_wave_cycles': (S2.get('SQ_ACTIVE_INST_LDS', 0.0) / S1['SQ_WAVE_CYCLES']) if S1.get('SQ_WAVE_CYCLES') else None,
+                 'valu_busy_frac': (S2.get('SQ_ACTIVE_INST_VALU', 0.0) / S1['SQ_WAVE_CYCLES']) if S1.get('SQ_WAVE_CYCLES') else None})
+json.dump(summ, open(os.path.join(dst, 'pmc_summary.json'), 'w'), indent=1)
+print(open(os.path.join(dst, 'timed_region.txt')).read())
+print(json.dumps({k: v for k, v in summ.items() if k != 'raw_counters_per_launch'}, indent=1))
