@@ -136,7 +136,7 @@ __global__ void srbm_k_init(const SrbmParams* __restrict__ Pp, SrbmInst* __restr
     I.init_time = 0; I.alpha = 0; I.cost = 0; I.eq_violation = 0; I.step_norm = 0; I.qp_cost = 0; I.res_primal = 0; I.res_dual = 0; I.gap = 0;
     I.status = SRBM_UNSOLVED; I.qp_iters = 0; I.n = 0; I.m = 0; I.n_eq = 0; I.n_ineq = 0; I.nfv = 0; I.npv = 0; I.n_td = 0; I.n_samples = 0;
     I.err = 0; I.run_num = 0; I.acc_iters = 0; I.acc_flops = 0;
-    I.cost_sum = 0; I.acc_mfma = 0; I.err_acc = 0; I.n_solves = 0; I.n_not_solved = 0; I.n_maxiter = 0;
+    I.cost_sum = 0; I.merit_dd = 0; I.acc_mfma = 0; I.err_acc = 0; I.n_solves = 0; I.n_not_solved = 0; I.n_maxiter = 0;
 }
 
 __global__ void srbm_k_warm_start(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, const double* __restrict__ states) {
@@ -511,6 +511,13 @@ int srbm_set_quadratic_final_cost(srbm_batch* h, const double* Phi144) {
 int srbm_set_linear_final_cost(srbm_batch* h, const double* w12) {
     if (!h || !w12) return fail("bad arguments");
     std::memcpy(h->hp.Phi_w, w12, sizeof(double) * 12);
+    h->params_dirty = true;
+    return 0;
+}
+// MPC::AddForceCost (mpc.cpp:791-802): weight on every force spline variable
+int srbm_add_force_cost(srbm_batch* h, double weight) {
+    if (!h) return fail("bad arguments");
+    h->hp.force_cost = weight;
     h->params_dirty = true;
     return 0;
 }
@@ -1322,6 +1329,15 @@ int srbm_get_cost(srbm_batch* h, double* cost) {
     std::vector<SrbmInst> v;
     if (fetch_insts(h, v)) return -1;
     for (int b = 0; b < h->batch; b++) cost[b] = v[b].cost;
+    return 0;
+}
+// merit[b] = cost + mu |dynamics defect|_1 of the trajectory after the last solve (MPC::GetMeritValue, mpc.cpp:749-753, mu = 5000) and
+// the directional derivative of the merit along the last step (GetMeritGradient, :783-788): the 'Merit' / 'Merit dd' columns
+int srbm_get_merit(srbm_batch* h, double* merit, double* merit_dd) {
+    if (!h || !merit) return fail("bad arguments");
+    std::vector<SrbmInst> v;
+    if (fetch_insts(h, v)) return -1;
+    for (int b = 0; b < h->batch; b++) { merit[b] = v[b].cost + h->hp.merit_mu * v[b].eq_violation; if (merit_dd) merit_dd[b] = v[b].merit_dd; }
     return 0;
 }
 int srbm_get_avg_cost(srbm_batch* h, double* avg) {

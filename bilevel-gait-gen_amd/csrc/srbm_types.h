@@ -61,6 +61,7 @@ typedef struct SrbmInst {
        (kernel 1 restarts them), these keep every error bit raised and count the solves by outcome; cost_sum / n_solves is
        MPC::GetAvgCost (mpc.cpp:991-998: mean of the cost_ entries RecordStats pushes, one per solve) */
     double cost_sum;
+    double merit_dd;                              /* directional derivative of the L1 merit along the step of the last solve (mpc.cpp:783-788; the 'Merit dd' column of the statistics log) */
     double acc_mfma;                              /* v_mfma_f64_16x16x4_f64 instructions EXECUTED (per wave) by the condensing and IPM phases: the executed-flop side of the roofline */
     int err_acc, n_solves, n_not_solved, n_maxiter;       /* n_not_solved: status not in {Solved, SolvedInacc}; n_maxiter: of those, MaxIter */
 } SrbmInst;

@@ -239,6 +239,14 @@ class BatchMPC:
         self._chk(self.L.srbm_get_cost(self.h, _d(a)))
         return a
 
+    def merit(self):
+        m = np.zeros(self.batch); d = np.zeros(self.batch)
+        self._chk(self.L.srbm_get_merit(self.h, _d(m), _d(d)))
+        return m, d
+
+    def add_force_cost(self, weight):
+        self._chk(self.L.srbm_add_force_cost(self.h, C.c_double(weight)))
+
     def avg_cost(self):
         a = np.zeros(self.batch)
         self._chk(self.L.srbm_get_avg_cost(self.h, _d(a)))
@@ -343,7 +351,8 @@ class BatchMPC:
 
     # ---- the reference's statistics log ----
     def print_stat_header(self, fh):
-        """header block of MPC::PrintStatLineToFile (mpc.cpp:901-939), same field widths"""
+        """header block of MPC::PrintStatLineToFile (mpc.cpp:901-939), same field widths.  (std::left is set on the stream while
+        the header is written and stays set: every column of the table is LEFT aligned in its 15 characters.)"""
         cw, tw = 15, 150
         c = self.cfg
         fh.write('-' * tw + '\n' + ' ' * (tw // 2 - 7) + 'MPC Statistics\n')
@@ -352,19 +361,18 @@ class BatchMPC:
         fh.write('Force cost: %g\nFoot offset: %g\nSwing height: %g\n' % (c['force_cost'], c['foot_offset'], c['swing_height']))
         fh.write('-' * tw + '\n')
         cols = ['Solve #', 'Time (ms)', 'Constraints', 'Step Norm', 'Alpha', 'Cost', 'Merit', 'Merit dd', 'Solve Type', 'QP Cost']
-        fh.write(''.join(n.rjust(cw) for n in cols) + '\n' + '-' * tw + '\n')
+        fh.write(''.join(n.ljust(cw) for n in cols) + '\n' + '-' * tw + '\n')
 
     def print_stat_line(self, fh, solve_number, time_ms, inst=0):
         """one table row of MPC::PrintStatLineToFile (mpc.cpp:974-989) for instance `inst` from the last solve.  Merit =
-        cost + mu * L1 dynamics defect (mpc.cpp:749-757, mu = 5000); the directional derivative is not kept on the device
-        and is printed as '-'."""
+        cost + mu * L1 dynamics defect (mpc.cpp:749-757, mu = 5000), Merit dd = its directional derivative along the step."""
         cw = 15
         st, err = self.status()
         s = self.stats()[inst]
-        merit = s[1] + 5000.0 * s[2]
-        vals = ['%d' % solve_number, '%g' % time_ms, '%g' % s[2], '%g' % s[3], '%g' % s[0], '%g' % s[1], '%g' % merit, '-',
+        merit, merit_dd = self.merit()
+        vals = ['%d' % solve_number, '%g' % time_ms, '%g' % s[2], '%g' % s[3], '%g' % s[0], '%g' % s[1], '%g' % merit[inst], '%g' % merit_dd[inst],
                 SOLVE_TYPE_NAMES.get(int(st[inst]), 'Other'), '%g' % self.qp_cost()[inst]]
-        fh.write(''.join(v.rjust(cw) for v in vals) + '\n')
+        fh.write(''.join(v.ljust(cw) for v in vals) + '\n')
 
     # ---- measurement aids ----
     def enable_kernel_timing(self, max_launches):

@@ -48,6 +48,8 @@ int srbm_add_quadratic_tracking_cost(srbm_batch* h, const double* state_des12, c
 /* MPC::SetQuadraticFinalCost / SetLinearFinalCost (mpc/mpc.cpp:137-151) */
 int srbm_set_quadratic_final_cost(srbm_batch* h, const double* Phi144);
 int srbm_set_linear_final_cost(srbm_batch* h, const double* w12);
+/* MPC::AddForceCost (mpc/mpc.cpp:791-802): weight of every force spline variable (replaces srbm_mpc_info.force_cost) */
+int srbm_add_force_cost(srbm_batch* h, double weight);
 /* MPC::SetStateTrajectoryWarmStart (mpc/mpc.cpp:700-706): states[batch][13], replicated over the horizon */
 int srbm_set_state_trajectory_warm_start(srbm_batch* h, const double* states);
 /* ClarabelInterface tolerances (mpc/qp/clarabel_interface.cpp:18-27,165-175) for the on-device IPM.
@@ -124,6 +126,9 @@ int srbm_get_ee_box_center(const srbm_batch* h, double* centers);
 /* MPC::GetCost (cost of prev_qp_sol, cost[batch]) and MPC::GetAvgCost (mpc/mpc.cpp:991-998: mean over all solves so far) */
 int srbm_get_cost(srbm_batch* h, double* cost);
 int srbm_get_avg_cost(srbm_batch* h, double* avg_cost);
+/* MPC::GetMeritValue / GetMeritGradient of the last solve (mpc/mpc.cpp:749-753, :783-788): the 'Merit' and 'Merit dd' columns of
+ * MPC::PrintStatLineToFile; merit_dd may be NULL */
+int srbm_get_merit(srbm_batch* h, double* merit, double* merit_dd);
 
 /* MPC::UpdateContactTimes (mpc/mpc.cpp:1085-1088): times[batch][4][max_contacts], counts must match the current
  * number of contact knots of every foot */

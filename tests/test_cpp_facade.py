@@ -26,6 +26,8 @@ def write_cfg_inc(cfg, path):
         f.write(arr('kBox', cfg['ee_box_size'])); f.write(arr('kIr', np.array(cfg['Ir']).reshape(-1)))
         f.write(arr('kHip', np.array(cfg['hip_xy']).reshape(-1))); f.write(arr('kQdiag', cfg['Q_srbd_diag']))
         f.write(arr('kInit', cfg['srb_init'])); f.write(arr('kTarget13', tgt)); f.write(arr('kTargetTangent', tt))
+        gold = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'a1_constants_a1_configuration.json')))
+        f.write(arr('kInitConfig', gold['source']['init_config']))
 
 
 def build_program(tmpdir):
@@ -78,3 +80,112 @@ def test_cpp_host_side_equals_ctypes_path(tmp_path):
     assert np.array_equal(np.array(vals['grad']), grad[0, :20])
     assert np.array_equal(np.array(vals['step']), step[0, :20])
     assert np.array_equal(np.array(vals['x']), x[0, :40])
+
+
+# ---------------- include/mpc_facade/mpc.h: the reference's own class names and signatures ----------------
+def build_callsites(tmpdir):
+    cfg = host.load_config('a1_configuration')
+    host.build()
+    write_cfg_inc(cfg, os.path.join(tmpdir, 'cfg.inc'))
+    exe = os.path.join(tmpdir, 'controller_callsites')
+    libdir = os.path.dirname(host.LIB_PATH)
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), '-I', tmpdir,
+                           os.path.join(CPP, 'controller_callsites.cpp'), '-o', exe, '-L', libdir, '-lsrbm_rti', '-Wl,-rpath,' + libdir])
+    return cfg, exe
+
+
+def parse_dump(out):
+    vals = {}
+    for ln in out.strip().splitlines():
+        parts = ln.split()
+        if len(parts) == 3:
+            try:
+                vals.setdefault(parts[0], []).append(float(parts[2]))
+            except ValueError:
+                pass
+    return vals
+
+
+def test_reference_call_sites_compile_against_the_mpc_facade(tmp_path):
+    """the statements of controllers/mpc_controller.cpp:57-108,286-399,518-566, transcribed in
+    tests/cpp/controller_callsites.cpp with the MPC, the gait optimiser and the trajectory held by value, compile warning-free
+    against include/mpc_facade/mpc.h (namespace mpc, the reference's signatures) and link against the C-ABI library."""
+    cfg, exe = build_callsites(str(tmp_path))
+    assert os.path.exists(exe)
+
+
+def test_facade_urdf_reader_reproduces_the_model_constants(tmp_path):
+    """MPC(const MPCInfo&, const std::string& robot_urdf) gets mass, Ir and the hip origins from the URDF as the reference does
+    through pinocchio (mpc/models/model.cpp:27, single_rigid_body_model.cpp:33-37,258-308).  Runs where the reference's URDF
+    asset is present (this container; not the GPU box), against the committed fixture of oracle/tools/a1_constants.py."""
+    urdf = '/root/reference/models/a1_description/urdf/a1.urdf'
+    if not os.path.exists(urdf):
+        pytest.skip('reference assets not present on this box')
+    cfg, exe = build_callsites(str(tmp_path))
+    vals = parse_dump(subprocess.check_output([exe, urdf, '0'], text=True))
+    gold = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'a1_constants_a1_configuration.json')))
+    assert abs(vals['urdf_mass'][0] - gold['mass']) < 1e-12 and abs(gold['mass'] - 13.741) < 1e-9
+    assert np.abs(np.array(vals['urdf_Ir']) - np.array(gold['Ir']).reshape(-1)).max() < 1e-12
+    hips = np.array([gold['hip_xy'][k] for k in ('FL', 'FR', 'RL', 'RR')]).reshape(-1)
+    assert np.abs(np.array(vals['urdf_hip']) - hips).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_mpc_facade_runs_the_controller_protocol_like_the_ctypes_path(tmp_path):
+    """The transcribed controller loop (11 ticks, gait step every 5th: two GaitOpt + two LineSearch) through mpc::MPCSingleRigidBody /
+    mpc::GaitOptimizer equals the same call sequence through the Python binding: same library underneath, so bit-identical."""
+    cfg, exe = build_callsites(str(tmp_path))
+    TICKS, F = 11, 5
+    vals = parse_dump(subprocess.check_output([exe, '-', str(TICKS), str(F)], text=True))
+    # header block of the log the program wrote through MPC::PrintStatLineToFile
+    log = open('/tmp/mpc_facade_log.txt').read().splitlines()
+    assert log[0] == '-' * 150 and 'MPC Statistics' in log[1] and log[2] == 'Number of nodes: 20'
+    assert len([l for l in log if l[:1].isdigit()]) == TICKS and all(len(l.rstrip()) <= 150 for l in log)
+    s0 = np.array(cfg['srb_init'], float)
+    ee0 = np.array([[0.2, 0.2, 0], [0.2, -0.2, 0], [-0.2, 0.2, 0], [-0.2, -0.2, 0]], float)
+    g = host.BatchMPC(cfg, 1)
+    g.set_state_trajectory_warm_start(s0)
+    g.add_force_cost(cfg['force_cost'])
+    g.create_initial_run(s0, ee0)
+    gait = host.BatchGaitOptimizer(g)
+    state, ee = s0, ee0.reshape(1, 12)
+    traj = g.get_trajectory()[0]
+    contact = traj.get_contacts(0.0)
+    ready, n_ls, ls_cost = False, 0, 0.0
+    for run in range(TICKS):
+        t = run * cfg['integrator_dt']
+        if run > 0:
+            state = traj.get_states()[1]
+            ee = np.array([traj.get_end_effector_location(e, t) for e in range(4)]).reshape(1, 12)
+            contact = traj.get_contacts(t)
+        g.adjust_for_current_contacts(t, np.array(contact, np.int32))
+        if run % F == 0 and run > 0 and ready:
+            imin, costs = gait.line_search(state, t, ee)
+            ready = False; n_ls += 1; ls_cost = costs[0, imin[0]]
+        elif (run + 1) % F == 0 and run > 0:
+            g.get_real_time_update(state, t, ee)
+            ready = g.status()[0][0] == 0
+            if ready:
+                gait.compute_sensitivity(); gait.compute_gradient(); gait.gradient(); gait.optimize_contact_times(t)
+        else:
+            g.get_real_time_update(state, t, ee); ready = False
+        traj = g.get_trajectory()[0]
+    avg = g.avg_cost()[0]
+    tn = TICKS * cfg['integrator_dt']
+    state = traj.get_states()[1]
+    ee = np.array([traj.get_end_effector_location(e, tn) for e in range(4)]).reshape(1, 12)
+    g.get_real_time_update(state, tn, ee)
+    assert vals['copy_equal'] == [1.0] and vals['line_searches'] == [float(n_ls)] and n_ls == 2 and vals['run_num'] == [float(TICKS)]
+    assert vals['no_match'] == [0.0]
+    sz = g.sizes()[0]
+    assert vals['n'] == [float(sz[0])] and vals['m'] == [float(sz[1])] and vals['quality'] == [float(g.status()[0][0])]
+    assert np.array_equal(np.array(vals['x']), g.qp_solution()[0, :40])
+    assert vals['cost'][0] == g.cost()[0] and vals['avg_cost'][0] == avg and vals['ls_cost'][0] == ls_cost
+    assert vals['mass'][0] == cfg['mass'] and vals['manifold'] == [13.0]
+    t2 = g.get_trajectory()[0]
+    f = np.array([t2.get_force(e, tn + 0.013) for e in range(4)]).reshape(-1)
+    p = np.array([t2.get_end_effector_location(e, tn + 0.013) for e in range(4)]).reshape(-1)
+    assert np.array_equal(np.array(vals['force']), f) and np.array_equal(np.array(vals['pos']), p)
+    assert np.array_equal(np.array(vals['contact_time']), np.concatenate(t2.get_contact_times()))
+    assert np.array_equal(np.array(vals['box_center']), g.ee_box_center().reshape(-1))
+    assert vals['viz'] == [5.0, 21.0]
