@@ -10,6 +10,7 @@
 #include "srbm_k4_update.hiph"
 #include "srbm_gait.hiph"
 #include "srbm_plant.hiph"
+#include "srbm_ik.hiph"
 #include "../../include/srbm_rti.h"
 
 static thread_local std::string g_err;
@@ -236,6 +237,78 @@ __global__ void srbm_k_set_contact_times(const SrbmParams* __restrict__ Pp, Srbm
     const int b = w / SRBM_NEE, ee = w % SRBM_NEE;
     SrbmInst& I = insts[b];
     srbm_apply_contact_times(I, ee, times + ((size_t)b * SRBM_NEE + ee) * ld, srbm_num_contacts(I, ee));
+}
+
+// ---------------- trajectory -> whole-body targets (srbm_ik.hiph) ----------------
+__device__ __forceinline__ const SrbmLegs& srbm_legs(const SrbmParams& P) { return *reinterpret_cast<const SrbmLegs*>(&P.legs[0][0][0]); }
+__global__ void srbm_k_forward_kinematics(const SrbmParams* __restrict__ Pp, const double* __restrict__ q, double* __restrict__ ee) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= Pp->batch) return;
+    ik_forward_kinematics(srbm_legs(*Pp), q + (size_t)b * 19, ee + (size_t)b * 12);
+}
+__global__ void srbm_k_inverse_kinematics(const SrbmParams* __restrict__ Pp, const double* __restrict__ state, const double* __restrict__ ee,
+                                          const double* __restrict__ q_guess, double* __restrict__ q_out, int* __restrict__ iters, int* __restrict__ status) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= Pp->batch) return;
+    double q[19];
+    for (int i = 0; i < 19; i++) q[i] = q_guess[(size_t)b * 19 + i];
+    int it[4];
+    status[b] = ik_inverse_kinematics(srbm_legs(*Pp), state + (size_t)b * 13, ee + (size_t)b * 12, q, it);
+    for (int i = 0; i < 19; i++) q_out[(size_t)b * 19 + i] = q[i];
+    for (int i = 0; i < 4; i++) iters[b * 4 + i] = it[i];
+}
+// MPCController::GetTargetsFromTraj (controllers/mpc_controller.cpp:414-511) on the current trajectory of every instance
+__global__ void srbm_k_targets_from_traj(const SrbmParams* __restrict__ Pp, const SrbmInst* __restrict__ insts, const double* __restrict__ time_in,
+                                         double* __restrict__ q_des, double* __restrict__ v_des, double* __restrict__ force_des, int* __restrict__ status) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= Pp->batch) return;
+    const SrbmParams& P = *Pp;
+    const SrbmInst& I = insts[b];
+    const int N = P.N;
+    const double t0 = I.init_time, dt = P.dt;
+    double time = time_in[b];
+    if (time < t0) time = t0;
+    const int node = (int)ceil((time - t0) / dt);
+    int st = 0, err = 0;
+    if (node < 0 || node + 1 > N) { status[b] = 2; return; }          // GetState(node + 1) beyond the horizon: the reference's vector access throws
+    auto T = [&](int k) { return t0 + dt * k; };
+    double s1[13], s2[13];
+    const double* S = I.states;
+    if (node > 0) {
+        const double a = 1 - (T(node) - time) / (T(node) - T(node - 1));
+        for (int i = 0; i < 13; i++) s1[i] = (S[node * 13 + i] - S[(node - 1) * 13 + i]) * a + S[(node - 1) * 13 + i];
+        if (time + dt < T(node)) st = 2;                              // "bad interp."
+        const double c = 1 - (T(node + 1) - (time + dt)) / (T(node + 1) - T(node));
+        for (int i = 0; i < 13; i++) s2[i] = (S[(node + 1) * 13 + i] - S[node * 13 + i]) * c + S[node * 13 + i];
+    } else {
+        const double a = 1 - (T(1) - time) / (T(1) - T(0));
+        const double c = 1 - (T(1) - (time + dt)) / (T(1) - T(0));
+        for (int i = 0; i < 13; i++) { s1[i] = (S[13 + i] - S[i]) * a + S[i]; s2[i] = (S[13 + i] - S[i]) * c + S[i]; }
+    }
+    double ee1[12], ee2[12], F[12];
+    for (int ee = 0; ee < SRBM_NEE; ee++) {
+        const FootView f{I.knot_t[ee], I.kind[ee], I.nk[ee]};
+        srbm_posxy_value(f, &I.pval[ee][0][0], time, ee1 + 3 * ee, &err);
+        ee1[3 * ee + 2] = srbm_posz_value(f, time, P.swing_height, P.foot_offset, &err);
+        srbm_posxy_value(f, &I.pval[ee][0][0], time + dt, ee2 + 3 * ee, &err);
+        ee2[3 * ee + 2] = srbm_posz_value(f, time + dt, P.swing_height, P.foot_offset, &err);
+        srbm_force_value(f, &I.fval[ee][0][0][0], time, F + 3 * ee, &err);
+    }
+    if (err) st = 2;
+    double q[19], q2[19];
+    for (int i = 0; i < 19; i++) q[i] = q_des[(size_t)b * 19 + i];
+    int it[4];
+    const SrbmLegs& L = srbm_legs(P);
+    if (ik_inverse_kinematics(L, s1, ee1, q, it) && st == 0) st = 1;
+    for (int i = 0; i < 19; i++) q2[i] = q[i];
+    if (ik_inverse_kinematics(L, s2, ee2, q2, it) && st == 0) st = 1;
+    double* v = v_des + (size_t)b * 18;
+    for (int i = 0; i < 3; i++) v[i] = s1[3 + i] / P.mass;
+    for (int i = 0; i < 3; i++) v[3 + i] = P.Ir_inv[3 * i] * s1[10] + P.Ir_inv[3 * i + 1] * s1[11] + P.Ir_inv[3 * i + 2] * s1[12];
+    for (int j = 0; j < 12; j++) v[6 + j] = (-q[7 + j] + q2[7 + j]) / dt;
+    for (int i = 0; i < 19; i++) q_des[(size_t)b * 19 + i] = q[i];
+    for (int i = 0; i < 12; i++) force_des[(size_t)b * 12 + i] = F[i];
+    status[b] = st;
 }
 
 // ---------------- host helpers ----------------
@@ -1375,6 +1448,82 @@ int srbm_get_executed_mfma(srbm_batch* h, double* total) {
     double t = 0;
     for (auto& I : v) t += I.acc_mfma;
     *total = t;
+    return 0;
+}
+
+// ---------------- row f3: whole-body targets ----------------
+int srbm_set_leg_kinematics(srbm_batch* h, const srbm_leg_kinematics* legs) {
+    if (!h || !legs) return fail("bad arguments");
+    std::memcpy(h->hp.legs, legs->origin, sizeof(h->hp.legs));
+    h->hp.has_legs = 1;
+    h->params_dirty = true;
+    return 0;
+}
+static int need_legs(srbm_batch* h) { return h->hp.has_legs ? 0 : fail("the leg geometry has not been set (srbm_set_leg_kinematics)"); }
+int srbm_forward_kinematics(srbm_batch* h, const double* q, double* ee) {
+    if (!h || !q || !ee) return fail("bad arguments");
+    if (need_legs(h)) return -1;
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    const size_t B = h->batch;
+    void* dv = nullptr;
+    if (batch_scratch(h, sizeof(double) * (19 + 12) * B, &dv)) return -1;
+    double* dq = static_cast<double*>(dv);
+    double* de = dq + 19 * B;
+    HIPCHK(hipMemcpyAsync(dq, q, sizeof(double) * 19 * B, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(srbm_k_forward_kinematics, dim3((h->batch + 63) / 64), dim3(64), 0, h->stream, h->dp, dq, de);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(ee, de, sizeof(double) * 12 * B, hipMemcpyDeviceToHost));
+    return 0;
+}
+int srbm_inverse_kinematics(srbm_batch* h, const double* state, const double* ee, const double* q_guess, double* q_out, int* iters, int* status) {
+    if (!h || !state || !ee || !q_guess || !q_out) return fail("bad arguments");
+    if (need_legs(h)) return -1;
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    const size_t B = h->batch;
+    void* dv = nullptr;
+    if (batch_scratch(h, sizeof(double) * (13 + 12 + 19 + 19) * B + sizeof(int) * 5 * B, &dv)) return -1;
+    double* ds = static_cast<double*>(dv);
+    double* de = ds + 13 * B;
+    double* dg = de + 12 * B;
+    double* dq = dg + 19 * B;
+    int* di = reinterpret_cast<int*>(dq + 19 * B);
+    int* dst = di + 4 * B;
+    HIPCHK(hipMemcpyAsync(ds, state, sizeof(double) * 13 * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(de, ee, sizeof(double) * 12 * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dg, q_guess, sizeof(double) * 19 * B, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(srbm_k_inverse_kinematics, dim3((h->batch + 63) / 64), dim3(64), 0, h->stream, h->dp, ds, de, dg, dq, di, dst);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(q_out, dq, sizeof(double) * 19 * B, hipMemcpyDeviceToHost));
+    if (iters) HIPCHK(hipMemcpy(iters, di, sizeof(int) * 4 * B, hipMemcpyDeviceToHost));
+    if (status) HIPCHK(hipMemcpy(status, dst, sizeof(int) * B, hipMemcpyDeviceToHost));
+    return 0;
+}
+int srbm_get_targets_from_traj(srbm_batch* h, const double* time, double* q_des, double* v_des, double* force_des, int* status) {
+    if (!h || !time || !q_des || !v_des || !force_des) return fail("bad arguments");
+    if (need_legs(h)) return -1;
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    const size_t B = h->batch;
+    void* dv = nullptr;
+    if (batch_scratch(h, sizeof(double) * (1 + 19 + 18 + 12) * B + sizeof(int) * B, &dv)) return -1;
+    double* dt_ = static_cast<double*>(dv);
+    double* dq = dt_ + B;
+    double* dvv = dq + 19 * B;
+    double* df = dvv + 18 * B;
+    int* dst = reinterpret_cast<int*>(df + 12 * B);
+    HIPCHK(hipMemcpyAsync(dt_, time, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dq, q_des, sizeof(double) * 19 * B, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(srbm_k_targets_from_traj, dim3((h->batch + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts, dt_, dq, dvv, df, dst);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(q_des, dq, sizeof(double) * 19 * B, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(v_des, dvv, sizeof(double) * 18 * B, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(force_des, df, sizeof(double) * 12 * B, hipMemcpyDeviceToHost));
+    if (status) HIPCHK(hipMemcpy(status, dst, sizeof(int) * B, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -43,6 +43,8 @@ typedef struct SrbmParams {
     double Q[144], w[12], Phi[144], Phi_w[12];
     double merit_mu, td_fraction;   /* mpc.cpp:65, :73 */
     double tol_gap_abs, tol_gap_rel, tol_feas;
+    double legs[SRBM_NEE][4][3];    /* leg geometry for the IK of row f3 (srbm_ik.hiph): joint origins hip / thigh / calf / foot */
+    int has_legs, pad2;
 } SrbmParams;
 
 typedef struct SrbmInst {

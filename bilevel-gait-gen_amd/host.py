@@ -184,6 +184,9 @@ class BatchMPC:
         self.add_quadratic_tracking_cost(des, Q)
         self.set_quadratic_final_cost(Q)
         self.set_linear_final_cost(-1 * Q @ des)
+        if 'leg_origins' in cfg:            # leg geometry for the whole-body targets (row f3)
+            lo = np.ascontiguousarray(cfg['leg_origins'], dtype=np.float64).reshape(4, 4, 3)
+            self._chk(self.L.srbm_set_leg_kinematics(self.h, _d(lo)))
 
     def close(self):
         if self.h:
@@ -348,6 +351,27 @@ class BatchMPC:
         t = np.ascontiguousarray(np.broadcast_to(np.asarray(time, dtype=np.float64), (self.batch,)))
         c = np.ascontiguousarray(np.broadcast_to(np.asarray(in_contact, dtype=np.int32), (self.batch, 4)))
         self._chk(self.L.srbm_adjust_for_current_contacts(self.h, _d(t), _i(c)))
+
+    # ---- trajectory -> whole-body targets ----
+    def forward_kinematics(self, q):
+        """SingleRigidBodyModel::GetEndEffectorLocations: q[batch][19] -> [batch][4][3]"""
+        qq = self._bcast(q, 19); ee = np.zeros((self.batch, 4, 3))
+        self._chk(self.L.srbm_forward_kinematics(self.h, _d(qq), _d(ee)))
+        return ee
+
+    def inverse_kinematics(self, state, ee, q_guess):
+        """SingleRigidBodyModel::InverseKinematics for every instance -> (q [batch][19], iterations [batch][4], status [batch])"""
+        s = self._bcast(state, 13); e = self._bcast(ee, 12); g = self._bcast(q_guess, 19)
+        q = np.zeros((self.batch, 19)); it = np.zeros((self.batch, 4), np.int32); st = np.zeros(self.batch, np.int32)
+        self._chk(self.L.srbm_inverse_kinematics(self.h, _d(s), _d(e), _d(g), _d(q), _i(it), _i(st)))
+        return q, it, st
+
+    def get_targets_from_traj(self, time, q_des):
+        """MPCController::GetTargetsFromTraj on the current trajectories -> (q_des, v_des [batch][18], force_des [batch][4][3], status)"""
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(time, dtype=np.float64), (self.batch,)))
+        q = self._bcast(q_des, 19).copy(); v = np.zeros((self.batch, 18)); f = np.zeros((self.batch, 4, 3)); st = np.zeros(self.batch, np.int32)
+        self._chk(self.L.srbm_get_targets_from_traj(self.h, _d(t), _d(q), _d(v), _d(f), _i(st)))
+        return q, v, f, st
 
     # ---- the reference's statistics log ----
     def print_stat_header(self, fh):

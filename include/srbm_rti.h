@@ -184,6 +184,27 @@ int srbm_gait_rti_advance(srbm_gait* g, int first_run_num, int steps, int gait_o
 /* solver status / error bits of the candidates of the last line search: status[batch*10], err[batch*10] */
 int srbm_gait_get_candidate_status(srbm_gait* g, int* status, int* err);
 
+/* ---- trajectory -> whole-body targets: the step right downstream of the MPC in the reference's
+ * controller.  q = [base position (3), base quaternion xyzw (4), 12 joint angles in pinocchio's model order FL FR RL RR x
+ * (hip, thigh, calf)]; v = [base linear, base angular velocity (base frame), 12 joint rates]. ---- */
+/* leg geometry (what the reference reads from the URDF through pinocchio): per leg FL FR RL RR the origins of the hip joint in
+ * the trunk, the thigh joint in the hip, the calf joint in the thigh and the foot in the calf; joint axes x, y, y, no rotation in
+ * the origins (A1: models/a1_description/urdf/a1.urdf:363-466) */
+typedef struct srbm_leg_kinematics { double origin[4][4][3]; } srbm_leg_kinematics;
+int srbm_set_leg_kinematics(srbm_batch* h, const srbm_leg_kinematics* legs);
+/* SingleRigidBodyModel::GetEndEffectorLocations (mpc/models/single_rigid_body_model.cpp:443-455): q[batch][19] -> ee[batch][4][3] */
+int srbm_forward_kinematics(srbm_batch* h, const double* q, double* ee);
+/* SingleRigidBodyModel::InverseKinematics (mpc/models/single_rigid_body_model.cpp:314-425): damped least squares on (foot position,
+ * base pose), one foot after the other, eps 5e-6, step 0.1, <= 1000 iterations per foot.  state[batch][13] (base pose from it),
+ * ee[batch][4][3] desired foot positions, q_guess[batch][19] (joint part used) -> q_out[batch][19]; iters[batch][4] and
+ * status[batch] (0 converged, 1 not converged: the reference throws "IK did not converge.") may be NULL */
+int srbm_inverse_kinematics(srbm_batch* h, const double* state, const double* ee, const double* q_guess, double* q_out, int* iters, int* status);
+/* MPCController::GetTargetsFromTraj (controllers/mpc_controller.cpp:414-511) on the CURRENT trajectory of every instance at time[batch]:
+ * interpolated state -> IK at `time` and `time + dt` -> q_des (in: the previous q_des as the IK guess, out), v_des[batch][18],
+ * force_des[batch][4][3] = Trajectory::GetForce(ee, time).  status[batch]: 0 ok, 1 IK not converged, 2 time outside the trajectory
+ * ("bad interp." / spline range: the reference throws) */
+int srbm_get_targets_from_traj(srbm_batch* h, const double* time, double* q_des, double* v_des, double* force_des, int* status);
+
 /* ---- results (all copied to host) ---- */
 /* sizes[batch][8] = n, m, n_eq, n_ineq, n_force_vars, n_pos_vars, n_td_rows, n_force_samples */
 int srbm_get_sizes(srbm_batch* h, int* sizes);

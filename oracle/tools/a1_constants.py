@@ -87,6 +87,14 @@ def derive(urdf_path, init_config):
     base_p = np.array(init_config[0:3]); base_R = quat_xyzw_to_R(init_config[3:7])
     bodies = []     # (mass, com_world, I_world)
     hips = {}
+    leg_origins = {}      # per leg: origins of the hip, thigh and calf joints and of the foot frame in their parent link (row f3: the IK)
+    for j in joints:
+        for k, suffix in enumerate(('_hip_joint', '_thigh_joint', '_calf_joint', '_foot_fixed')):
+            if j['name'].endswith(suffix):
+                assert np.allclose(j['R'], np.eye(3)), j['name']
+                if k < 3:
+                    assert np.allclose(j['axis'], [1, 0, 0] if k == 0 else [0, 1, 0]), j['name']
+                leg_origins.setdefault(j['name'][:2], [None] * 4)[k] = [float(v) for v in j['xyz']]
     def walk(link, p, R):
         if links[link] is not None:
             m, c, Rl, I = links[link]
@@ -107,7 +115,7 @@ def derive(urdf_path, init_config):
         Iw += I + m * (d @ d * np.eye(3) - np.outer(d, d))
     Ir = base_R.T @ Iw @ base_R
     return dict(mass=mass, Ir=Ir.tolist(), com_in_base=(base_R.T @ (com - base_p)).tolist(),
-                hip_xy={k: [float(v[0]), float(v[1])] for k, v in hips.items()}, joint_order=order)
+                hip_xy={k: [float(v[0]), float(v[1])] for k, v in hips.items()}, joint_order=order, leg_origins=leg_origins)
 
 if __name__ == '__main__':
     ref = sys.argv[1] if len(sys.argv) > 1 else '/root/reference'

@@ -19,6 +19,8 @@ for cfg in ('a1_configuration', 'a1_gait_opt_config', 'a1_config_distr_rejection
     k = json.load(open(os.path.join(root, 'tests', 'golden', 'a1_constants_%s.json' % cfg)))
     c['mass'] = k['mass']; c['Ir'] = k['Ir']
     c['hip_xy'] = [k['hip_xy'][n] for n in ('FL', 'FR', 'RL', 'RR')]
+    c['leg_origins'] = [k['leg_origins'][n] for n in ('FL', 'FR', 'RL', 'RR')]      # row f3: hip / thigh / calf joint and foot-frame origins
+    c['init_config'] = k['source']['init_config']
     c['source'] = 'apps/%s.yaml + models/a1_description/urdf/a1.urdf' % cfg
     json.dump(c, open(os.path.join(out_dir, cfg + '.json'), 'w'), indent=1)
     print(cfg, {kk: c[kk] for kk in ('num_nodes', 'integrator_dt', 'friction_coef', 'force_bound')})

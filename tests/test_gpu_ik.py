@@ -1,0 +1,106 @@
+"""GPU parity of the trajectory -> whole-body-target step (csrc/srbm_ik.hiph through the C-ABI) against the
+numpy restatement oracle/ik_numpy.py (pinned by tests/test_oracle_ik.py; the reference has no fixture for this step).
+Iteration counts must be EQUAL (same algorithm, same path), joint angles agree to 1e-8."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle_py import OracleMPC, load_config
+from srbm_loader import host
+from bench import config_b_instance
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import ik_numpy as ik
+
+pytestmark = pytest.mark.gpu
+
+
+def setup(B):
+    cfg = load_config()
+    legs = np.array(cfg['leg_origins'])
+    q0 = np.array(cfg['init_config'], float)
+    g = host.BatchMPC(cfg, B)
+    return cfg, legs, q0, g
+
+
+def test_forward_and_inverse_kinematics_match_the_oracle():
+    B = 16
+    cfg, legs, q0, g = setup(B)
+    rng = np.random.default_rng(5)
+    q = np.tile(q0, (B, 1))
+    q[:, 7:] += rng.normal(size=(B, 12)) * 0.15
+    q[:, :3] += rng.normal(size=(B, 3)) * 0.05
+    quat = q[:, 3:7] + np.concatenate([rng.normal(size=(B, 3)) * 0.1, np.zeros((B, 1))], axis=1)
+    q[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    ee = g.forward_kinematics(q)
+    for b in range(B):
+        assert np.abs(ee[b] - ik.forward_kinematics(legs, q[b])).max() < 1e-13
+    # IK towards perturbed foot positions and base poses
+    state = np.zeros((B, 13))
+    state[:, :3] = q[:, :3] + rng.normal(size=(B, 3)) * 0.01
+    quat = q[:, 3:7] + np.concatenate([rng.normal(size=(B, 3)) * 0.02, np.zeros((B, 1))], axis=1)
+    state[:, 6:10] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    des = ee + rng.normal(size=(B, 4, 3)) * 0.02
+    qs, iters, st = g.inverse_kinematics(state, des.reshape(B, 12), q)
+    assert np.all(st == 0)
+    for b in range(B):
+        qo, ito, ok = ik.inverse_kinematics(legs, state[b], des[b], q[b])
+        assert ok and list(iters[b]) == ito, (b, iters[b], ito)
+        assert np.abs(qs[b] - qo).max() < 1e-8, (b, np.abs(qs[b] - qo).max())
+    back = g.forward_kinematics(qs)
+    assert np.abs(back - des).max() < 2e-5            # FK o IK = identity to the solver's tolerance (5e-6 per foot, feet in turn)
+    # an unreachable target is reported, never silently accepted (the reference throws "IK did not converge.")
+    far = des.copy(); far[0, 2] += [1.0, 0.0, -1.0]
+    _, it2, st2 = g.inverse_kinematics(state, far.reshape(B, 12), q)
+    assert st2[0] == 1 and it2[0, 2] == 1000 and np.all(st2[1:] == 0)
+
+
+def test_targets_from_trajectory_match_the_oracle():
+    """MPCController::GetTargetsFromTraj (mpc_controller.cpp:414-511) on the trajectories of a running batch"""
+    B = 8
+    cfg, legs, q0, g = setup(B)
+    states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees).reshape(B, 12)
+    g.set_state_trajectory_warm_start(states)
+    g.create_initial_run(states, ees)
+    g.rti_advance(0, 3); g.synchronize()
+    trajs = g.get_trajectory()
+    Ir_inv = np.linalg.inv(np.array(cfg['Ir']))
+    q_des = np.tile(q0, (B, 1))
+    for frac in (0.0, 0.37, 1.6):                       # at a node, inside the first interval, inside a later one
+        t = trajs[0].init_time + frac * cfg['integrator_dt']
+        q, v, f, st = g.get_targets_from_traj(t, q_des)
+        assert np.all(st == 0)
+        for b in range(B):
+            tr = trajs[b]
+            qo, vo, fo, ok = ik.targets_from_traj(legs, tr.get_states(), tr.init_time, tr.node_dt, cfg['mass'], Ir_inv,
+                                                  lambda e, tt: tr.get_end_effector_location(e, tt), lambda e, tt: tr.get_force(e, tt), t, q_des[b])
+            assert ok
+            assert np.abs(q[b] - qo).max() < 1e-8 and np.abs(v[b] - vo).max() < 1e-6 and np.abs(f[b] - fo).max() < 1e-9, (frac, b)
+        q_des = q
+    # beyond the horizon: reported (the reference's vector access / spline lookup throws)
+    _, _, _, st = g.get_targets_from_traj(trajs[0].init_time + 25 * cfg['integrator_dt'], q_des)
+    assert np.all(st == 2)
+
+
+def test_full_batch_targets_properties():
+    B = 256
+    cfg, legs, q0, g = setup(B)
+    states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees).reshape(B, 12)
+    g.set_state_trajectory_warm_start(states)
+    g.create_initial_run(states, ees)
+    g.rti_advance(0, 2); g.synchronize()
+    trajs = g.get_trajectory()
+    t = trajs[0].init_time + 0.4 * cfg['integrator_dt']
+    q, v, f, st = g.get_targets_from_traj(t, np.tile(q0, (B, 1)))
+    assert np.all(st == 0) and np.all(np.isfinite(q)) and np.all(np.isfinite(v))
+    fk = g.forward_kinematics(q)
+    _, pos, _ = g.eval_trajectory(t)
+    assert np.abs(fk - pos).max() < 2e-5                # the IK targets put the feet where the trajectory has them
+    ff, _, _ = g.eval_trajectory(t)
+    assert np.array_equal(f, ff)
+    assert np.abs(v[:, 6:]).max() < 100                 # the reference warns above 100 rad/s
