@@ -11,6 +11,7 @@
 #include "srbm_gait.hiph"
 #include "srbm_plant.hiph"
 #include "srbm_ik.hiph"
+#include "srbm_wbc.hiph"
 #include "../../include/srbm_rti.h"
 
 static thread_local std::string g_err;
@@ -36,6 +37,7 @@ struct srbm_batch {
     std::vector<int> ev_steps;        // RTI steps covered by each timed launch (1 for the stand-alone IPM kernel)
     size_t ev_used = 0;
     int gait_refs = 0;               // live srbm_gait handles borrowing this batch (and its stream)
+    SrbmWbcParams* d_wbc = nullptr;  // whole-body QP model and gains (row f3), set by srbm_set_wbc_model
     void* d_scratch = nullptr;       // staging buffer of the small host->device entry points (grown on demand, never per call)
     size_t scratch_bytes = 0;
 };
@@ -459,7 +461,7 @@ static void free_batch(srbm_batch* h) {
     (void)hipFree(h->dp); (void)hipFree(h->insts); (void)hipFree(h->works);
     (void)hipFree(h->d_state); (void)hipFree(h->d_time); (void)hipFree(h->d_ee);
     (void)hipFree(h->d_plant); (void)hipFree(h->d_push_time); (void)hipFree(h->d_push_impulse);
-    (void)hipFree(h->d_scratch);
+    (void)hipFree(h->d_scratch); (void)hipFree(h->d_wbc);
     for (auto e : h->ev_start) (void)hipEventDestroy(e);
     for (auto e : h->ev_stop) (void)hipEventDestroy(e);
     if (h->owns_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -1524,6 +1526,60 @@ int srbm_get_targets_from_traj(srbm_batch* h, const double* time, double* q_des,
     HIPCHK(hipMemcpy(v_des, dvv, sizeof(double) * 18 * B, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(force_des, df, sizeof(double) * 12 * B, hipMemcpyDeviceToHost));
     if (status) HIPCHK(hipMemcpy(status, dst, sizeof(int) * B, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int srbm_set_wbc_model(srbm_batch* h, const srbm_wbc_model* m) {
+    if (!h || !m) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    SrbmWbcParams w;
+    for (int b = 0; b < 13; b++) {
+        w.body[b].mass = m->body_mass[b];
+        for (int i = 0; i < 3; i++) w.body[b].com[i] = m->body_com[b][i];
+        for (int i = 0; i < 9; i++) w.body[b].I[i] = m->body_inertia[b][i];
+    }
+    for (int i = 0; i < 12; i++) { w.torque_bounds[i] = m->torque_bounds[i]; w.kp_joint[i] = m->kp_joint_gains[i]; w.kd_joint[i] = m->kd_joint_gains[i]; }
+    w.kv_pos = m->base_pos_gains[0]; w.kp_pos = m->base_pos_gains[1]; w.kv_ang = m->base_ang_gains[0]; w.kp_ang = m->base_ang_gains[1];
+    w.leg_weight = m->leg_tracking_weight; w.torso_weight = m->torso_tracking_weight; w.force_weight = m->force_tracking_weight;
+    w.friction = m->friction_coef; w.max_grf = m->max_grf;
+    if (!h->d_wbc) HIPCHK(hipMalloc(&h->d_wbc, sizeof(SrbmWbcParams)));
+    HIPCHK(hipMemcpy(h->d_wbc, &w, sizeof(w), hipMemcpyHostToDevice));
+    return 0;
+}
+int srbm_qp_control(srbm_batch* h, const double* q, const double* v, const int* contact, const double* q_des, const double* v_des,
+                    const double* force_des, double* control, double* qp_sol, int* status, double* qp_dump) {
+    if (!h || !q || !v || !contact || !q_des || !v_des || !force_des || !control) return fail("bad arguments");
+    if (need_legs(h)) return -1;
+    if (!h->d_wbc) return fail("the whole-body model has not been set (srbm_set_wbc_model)");
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    const size_t B = h->batch, DUMP = WBC_MMAX * WBC_NMAX + 2 * WBC_MMAX + 2 * WBC_NMAX;
+    void* dv = nullptr;
+    const size_t nd = (19 + 18 + 19 + 18 + 12 + 36 + WBC_NMAX + (qp_dump ? DUMP : 0)) * B;
+    if (batch_scratch(h, sizeof(double) * nd + sizeof(int) * 5 * B, &dv)) return -1;
+    double* dq = static_cast<double*>(dv);
+    double* dvl = dq + 19 * B;
+    double* dqd = dvl + 18 * B;
+    double* dvd = dqd + 19 * B;
+    double* dfd = dvd + 18 * B;
+    double* dctl = dfd + 12 * B;
+    double* dsol = dctl + 36 * B;
+    double* ddump = qp_dump ? dsol + WBC_NMAX * B : nullptr;
+    int* dcon = reinterpret_cast<int*>(static_cast<double*>(dv) + nd);
+    int* dst = dcon + 4 * B;
+    HIPCHK(hipMemcpyAsync(dq, q, sizeof(double) * 19 * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dvl, v, sizeof(double) * 18 * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dqd, q_des, sizeof(double) * 19 * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dvd, v_des, sizeof(double) * 18 * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dfd, force_des, sizeof(double) * 12 * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(dcon, contact, sizeof(int) * 4 * B, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(srbm_k_qp_control, dim3(h->batch), dim3(WBC_THREADS), 0, h->stream, h->dp, h->d_wbc, dq, dvl, dcon, dqd, dvd, dfd, dctl, dsol, dst, ddump);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(control, dctl, sizeof(double) * 36 * B, hipMemcpyDeviceToHost));
+    if (qp_sol) HIPCHK(hipMemcpy(qp_sol, dsol, sizeof(double) * WBC_NMAX * B, hipMemcpyDeviceToHost));
+    if (status) HIPCHK(hipMemcpy(status, dst, sizeof(int) * B, hipMemcpyDeviceToHost));
+    if (qp_dump) HIPCHK(hipMemcpy(qp_dump, ddump, sizeof(double) * DUMP * B, hipMemcpyDeviceToHost));
     return 0;
 }
 

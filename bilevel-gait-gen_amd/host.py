@@ -28,6 +28,14 @@ class MPCInfo(C.Structure):          # srbm_mpc_info
                 ('ee_box_size', C.c_double * 2), ('force_cost', C.c_double)]
 
 
+class WbcModel(C.Structure):         # srbm_wbc_model
+    _fields_ = [('body_mass', C.c_double * 13), ('body_com', (C.c_double * 3) * 13), ('body_inertia', (C.c_double * 9) * 13),
+                ('torque_bounds', C.c_double * 12), ('kp_joint_gains', C.c_double * 12), ('kd_joint_gains', C.c_double * 12),
+                ('base_pos_gains', C.c_double * 2), ('base_ang_gains', C.c_double * 2),
+                ('leg_tracking_weight', C.c_double), ('torso_tracking_weight', C.c_double), ('force_tracking_weight', C.c_double),
+                ('friction_coef', C.c_double), ('max_grf', C.c_double)]
+
+
 class Model(C.Structure):            # srbm_model
     _fields_ = [('mass', C.c_double), ('Ir', C.c_double * 9), ('hip_xy', C.c_double * 8)]
 
@@ -187,6 +195,18 @@ class BatchMPC:
         if 'leg_origins' in cfg:            # leg geometry for the whole-body targets (row f3)
             lo = np.ascontiguousarray(cfg['leg_origins'], dtype=np.float64).reshape(4, 4, 3)
             self._chk(self.L.srbm_set_leg_kinematics(self.h, _d(lo)))
+        if 'body_model' in cfg and 'torque_bounds' in cfg:        # whole-body QP of the low-level controller (row f3)
+            w = WbcModel()
+            for b, body in enumerate(cfg['body_model']):
+                w.body_mass[b] = body['mass']
+                w.body_com[b][:] = body['com']
+                w.body_inertia[b][:] = list(np.asarray(body['inertia'], float).reshape(-1))
+            w.torque_bounds[:] = [float(x) for x in cfg['torque_bounds']]
+            w.kp_joint_gains[:] = [float(x) for x in cfg['kp_joint_gains']]; w.kd_joint_gains[:] = [float(x) for x in cfg['kd_joint_gains']]
+            w.base_pos_gains[:] = [float(x) for x in cfg['base_pos_gains']]; w.base_ang_gains[:] = [float(x) for x in cfg['base_ang_gains']]
+            w.leg_tracking_weight = cfg['leg_tracking_weight']; w.torso_tracking_weight = cfg['torso_tracking_weight']
+            w.force_tracking_weight = cfg['force_tracking_weight']; w.friction_coef = cfg['friction_coef']; w.max_grf = cfg['force_bound']
+            self._chk(self.L.srbm_set_wbc_model(self.h, C.byref(w)))
 
     def close(self):
         if self.h:
@@ -372,6 +392,20 @@ class BatchMPC:
         q = self._bcast(q_des, 19).copy(); v = np.zeros((self.batch, 18)); f = np.zeros((self.batch, 4, 3)); st = np.zeros(self.batch, np.int32)
         self._chk(self.L.srbm_get_targets_from_traj(self.h, _d(t), _d(q), _d(v), _d(f), _i(st)))
         return q, v, f, st
+
+    def qp_control(self, q, v, contact, q_des, v_des, force_des, dump=False):
+        """QPControl::ComputeControlAction for every instance -> (control [batch][36], qp_sol [batch][30], status, iterations[, QP dump])"""
+        B = self.batch
+        qq = self._bcast(q, 19); vv = self._bcast(v, 18); qd = self._bcast(q_des, 19); vd = self._bcast(v_des, 18); fd = self._bcast(force_des, 12)
+        con = np.ascontiguousarray(np.broadcast_to(np.asarray(contact, dtype=np.int32), (B, 4)))
+        ctl = np.zeros((B, 36)); sol = np.zeros((B, 30)); st = np.zeros(B, np.int32)
+        dmp = np.zeros((B, 50 * 30 + 100 + 60)) if dump else None
+        self._chk(self.L.srbm_qp_control(self.h, _d(qq), _d(vv), _i(con), _d(qd), _d(vd), _d(fd), _d(ctl), _d(sol), _i(st), _d(dmp) if dump else None))
+        out = (ctl, sol, st & 255, st >> 8)
+        if dump:
+            A = dmp[:, :1500].reshape(B, 50, 30)
+            out += (dict(A=A, lb=dmp[:, 1500:1550], ub=dmp[:, 1550:1600], P=dmp[:, 1600:1630], w=dmp[:, 1630:1660]),)
+        return out
 
     # ---- the reference's statistics log ----
     def print_stat_header(self, fh):

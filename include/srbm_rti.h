@@ -205,6 +205,26 @@ int srbm_inverse_kinematics(srbm_batch* h, const double* state, const double* ee
  * ("bad interp." / spline range: the reference throws) */
 int srbm_get_targets_from_traj(srbm_batch* h, const double* time, double* q_des, double* v_des, double* force_des, int* status);
 
+/* QPControl (controllers/qp_control.cpp): the 1 kHz whole-body inverse-dynamics QP, for every instance of the batch.
+ * Model: the rigid bodies pinocchio builds from the URDF -- trunk, then FL FR RL RR x (hip, thigh, calf), links on fixed joints
+ * merged into their parent -- each with mass, centre of mass and rotational inertia about it (row-major 3x3) in the frame of
+ * its joint; gains and weights as the QPControl constructor takes them (qp_control.cpp:20-52: base_pos_gains = {kv, kp}, ...) */
+typedef struct srbm_wbc_model {
+    double body_mass[13], body_com[13][3], body_inertia[13][9];
+    double torque_bounds[12], kp_joint_gains[12], kd_joint_gains[12];
+    double base_pos_gains[2], base_ang_gains[2];
+    double leg_tracking_weight, torso_tracking_weight, force_tracking_weight, friction_coef, max_grf;
+} srbm_wbc_model;
+int srbm_set_wbc_model(srbm_batch* h, const srbm_wbc_model* model);
+/* QPControl::ComputeControlAction (qp_control.cpp:74-135) with the targets of UpdateTargetConfig / Vel / ForceTargets:
+ * q[batch][19], v[batch][18] measured; contact[batch][4] (0/1: in contact, measured and desired); q_des[batch][19], v_des[batch][18],
+ * force_des[batch][12] = 3 per foot IN CONTACT, stacked in foot order (the reference's force_target_).
+ * control[batch][36] = joint position targets (12), joint velocity targets (12), torques (12) -- all zero where the QP failed, as the
+ * reference returns; qp_sol[batch][30] = accelerations (18) then contact forces; status[batch] = SolveQuality | iterations << 8.
+ * qp_dump (may be NULL): the assembled QP in the reference's layout per instance: A[50][30], lb[50], ub[50], diag P[30], w[30]. */
+int srbm_qp_control(srbm_batch* h, const double* q, const double* v, const int* contact, const double* q_des, const double* v_des,
+                    const double* force_des, double* control, double* qp_sol, int* status, double* qp_dump);
+
 /* ---- results (all copied to host) ---- */
 /* sizes[batch][8] = n, m, n_eq, n_ineq, n_force_vars, n_pos_vars, n_td_rows, n_force_samples */
 int srbm_get_sizes(srbm_batch* h, int* sizes);

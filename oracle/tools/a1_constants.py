@@ -95,6 +95,32 @@ def derive(urdf_path, init_config):
                 if k < 3:
                     assert np.allclose(j['axis'], [1, 0, 0] if k == 0 else [0, 1, 0]), j['name']
                 leg_origins.setdefault(j['name'][:2], [None] * 4)[k] = [float(v) for v in j['xyz']]
+    # rigid bodies of the whole-body model (row f3, the 1 kHz QP): the trunk and the three moving links of every leg, every link
+    # hanging on a FIXED joint merged into its parent (what pinocchio's URDF parser does): mass, centre of mass and rotational
+    # inertia about it, in the frame of the body's joint (trunk: the floating-base frame)
+    def merged(link):
+        parts = []       # (m, c, I) in this link's frame
+        if links[link] is not None:
+            m, c, Rl, I = links[link]
+            parts.append((m, c, Rl @ I @ Rl.T))
+        for j in children.get(link, []):
+            if j['type'] == 'fixed':
+                for m, c, I in merged(j['child']):
+                    parts.append((m, j['xyz'] + j['R'] @ c, j['R'] @ I @ j['R'].T))
+        return parts
+    def lump(parts):
+        m = sum(p[0] for p in parts)
+        c = sum(p[0] * p[1] for p in parts) / m
+        I = np.zeros((3, 3))
+        for mi, ci, Ii in parts:
+            d = ci - c
+            I += Ii + mi * (d @ d * np.eye(3) - np.outer(d, d))
+        return dict(mass=float(m), com=[float(v) for v in c], inertia=I.tolist())
+    trunk = [jj['child'] for jj in joints if jj['name'] == 'floating_base'][0]
+    body_model = [lump(merged(trunk))]
+    for leg in ('FL', 'FR', 'RL', 'RR'):
+        for part in ('hip', 'thigh', 'calf'):
+            body_model.append(lump(merged('%s_%s' % (leg, part))))
     def walk(link, p, R):
         if links[link] is not None:
             m, c, Rl, I = links[link]
@@ -115,7 +141,7 @@ def derive(urdf_path, init_config):
         Iw += I + m * (d @ d * np.eye(3) - np.outer(d, d))
     Ir = base_R.T @ Iw @ base_R
     return dict(mass=mass, Ir=Ir.tolist(), com_in_base=(base_R.T @ (com - base_p)).tolist(),
-                hip_xy={k: [float(v[0]), float(v[1])] for k, v in hips.items()}, joint_order=order, leg_origins=leg_origins)
+                hip_xy={k: [float(v[0]), float(v[1])] for k, v in hips.items()}, joint_order=order, leg_origins=leg_origins, body_model=body_model)
 
 if __name__ == '__main__':
     ref = sys.argv[1] if len(sys.argv) > 1 else '/root/reference'

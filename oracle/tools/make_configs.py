@@ -21,6 +21,11 @@ for cfg in ('a1_configuration', 'a1_gait_opt_config', 'a1_config_distr_rejection
     c['hip_xy'] = [k['hip_xy'][n] for n in ('FL', 'FR', 'RL', 'RR')]
     c['leg_origins'] = [k['leg_origins'][n] for n in ('FL', 'FR', 'RL', 'RR')]      # row f3: hip / thigh / calf joint and foot-frame origins
     c['init_config'] = k['source']['init_config']
+    c['body_model'] = k['body_model']        # row f3: trunk + 12 moving links (mass, com, inertia in the joint frame), fixed links merged
+    for key in ('torque_bounds', 'base_pos_gains', 'base_ang_gains', 'kp_joint_gains', 'kd_joint_gains', 'leg_tracking_weight',
+                'torso_tracking_weight', 'force_tracking_weight'):      # the whole-body QP of controllers/qp_control.cpp
+        if key in y:
+            c[key] = y[key]
     c['source'] = 'apps/%s.yaml + models/a1_description/urdf/a1.urdf' % cfg
     json.dump(c, open(os.path.join(out_dir, cfg + '.json'), 'w'), indent=1)
     print(cfg, {kk: c[kk] for kk in ('num_nodes', 'integrator_dt', 'friction_coef', 'force_bound')})

@@ -1,0 +1,96 @@
+"""GPU parity of the batched whole-body QP controller (second half; csrc/srbm_wbc.hiph through the C-ABI) against
+the numpy restatement oracle/wbc_numpy.py (pinned by tests/test_oracle_wbc.py; the reference holds no fixture for this step).
+The assembled QP (A, lb, ub, P, w in the reference's row / column order) <= 1e-9, the minimiser and the torques <= 1e-6 relative."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from oracle_py import load_config, qp_solve
+from srbm_loader import host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import ik_numpy as ik
+import wbc_numpy as wbc
+
+pytestmark = pytest.mark.gpu
+CONTACTS = [[1, 1, 1, 1], [1, 0, 0, 1], [0, 1, 1, 0], [1, 1, 1, 0], [0, 0, 1, 0]]
+
+
+def make(B, seed=3):
+    cfg = load_config()
+    rng = np.random.default_rng(seed)
+    q0 = np.array(cfg['init_config'], float)
+    q = np.tile(q0, (B, 1))
+    q[:, :3] += rng.normal(size=(B, 3)) * 0.03
+    quat = q[:, 3:7] + np.concatenate([rng.normal(size=(B, 3)) * 0.05, np.zeros((B, 1))], axis=1)
+    q[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    q[:, 7:] += rng.normal(size=(B, 12)) * 0.1
+    v = rng.normal(size=(B, 18)) * 0.1
+    q_des = np.tile(q0, (B, 1)); q_des[:, 7:] += rng.normal(size=(B, 12)) * 0.02
+    v_des = rng.normal(size=(B, 18)) * 0.05
+    return cfg, q, v, q_des, v_des, rng
+
+
+def test_assembled_qp_and_solution_match_the_oracle():
+    B = len(CONTACTS) * 2
+    cfg, q, v, q_des, v_des, rng = make(B)
+    contact = np.array([CONTACTS[b % len(CONTACTS)] for b in range(B)], np.int32)
+    fdes = np.zeros((B, 12))
+    for b in range(B):
+        nc = contact[b].sum()
+        fdes[b, :3 * nc] = np.tile([1.0, -2.0, cfg['mass'] * 9.81 / nc], nc)
+    g = host.BatchMPC(cfg, B)
+    ctl, sol, st, iters, qp = g.qp_control(q, v, contact, q_des, v_des, fdes, dump=True)
+    robot = wbc.Robot(cfg)
+    for b in range(B):
+        nc = int(contact[b].sum())
+        n, m = 18 + 3 * nc, 6 + 7 * nc + 12 + nc
+        A, lb, ub, P, w, (M, Cv, gg, Js) = wbc.build_qp(robot, cfg, q[b], v[b], contact[b], q_des[b], v_des[b], fdes[b, :3 * nc])
+        assert np.abs(qp['A'][b, :m, :n] - A).max() < 1e-9, b
+        assert np.all(qp['A'][b, m:, :] == 0) and np.all(qp['A'][b, :, n:] == 0)
+        fin = np.abs(lb) < 1e29
+        assert np.abs(qp['lb'][b, :m][fin] - lb[fin]).max() < 1e-8 and np.all(qp['lb'][b, :m][~fin] < -1e29), b
+        assert np.abs(qp['ub'][b, :m] - ub).max() < 1e-8, b
+        assert np.abs(qp['P'][b, :n] - np.diag(P)).max() < 1e-12 and np.abs(qp['w'][b, :n] - w).max() < 1e-7 * max(1.0, np.abs(w).max()), b
+        xo, so = wbc.solve_qp(A, lb, ub, P, w, qp_solve)
+        assert st[b] <= 1 and so == 0, (b, st[b], so, iters[b])
+        scale = max(1.0, np.abs(xo).max())
+        assert np.abs(sol[b, :n] - xo).max() / scale < 1e-6, (b, np.abs(sol[b, :n] - xo).max() / scale)
+        co, _, _ = wbc.control_action(robot, cfg, q[b], v[b], contact[b], q_des[b], v_des[b], fdes[b, :3 * nc], qp_solve)
+        assert np.abs(ctl[b] - co).max() < 1e-6 * max(1.0, np.abs(co).max()), b
+        assert np.array_equal(ctl[b, :12], q_des[b, 7:]) and np.array_equal(ctl[b, 12:24], v_des[b, 6:])
+
+
+def test_full_batch_controller_properties():
+    """256 instances: every QP solves; the solution satisfies the floating-base dynamics, the torque limits, the friction pyramid and the
+    force bounds; standing still at the nominal configuration with the weight as the force target needs torques that hold the weight"""
+    B = 256
+    cfg, q, v, q_des, v_des, rng = make(B, seed=9)
+    contact = np.array([CONTACTS[b % 3] for b in range(B)], np.int32)
+    fdes = np.zeros((B, 12))
+    for b in range(B):
+        nc = contact[b].sum()
+        fdes[b, :3 * nc] = np.tile([0, 0, cfg['mass'] * 9.81 / nc], nc)
+    g = host.BatchMPC(cfg, B)
+    ctl, sol, st, iters, qp = g.qp_control(q, v, contact, q_des, v_des, fdes, dump=True)
+    assert np.all(st <= 1), np.unique(st, return_counts=True)          # Solved (or, at the noise floor, SolvedInacc)
+    print('whole-body QP, 256 instances: IPM iterations min %d median %d max %d, statuses %s' % (iters.min(), np.median(iters), iters.max(), dict(zip(*np.unique(st, return_counts=True)))))
+    assert iters.max() < 40
+    tb = np.array(cfg['torque_bounds'], float)
+    for b in range(0, B, 7):
+        nc = int(contact[b].sum()); n, m = 18 + 3 * nc, 6 + 7 * nc + 12 + nc
+        Ax = qp['A'][b, :m, :n] @ sol[b, :n]
+        assert np.all(Ax <= qp['ub'][b, :m] + 1e-7) and np.all(Ax >= qp['lb'][b, :m] - 1e-7), b
+        assert np.all(np.abs(ctl[b, 24:]) <= tb + 1e-6)
+        f = sol[b, 18:18 + 3 * nc].reshape(nc, 3)
+        assert np.all(f[:, 2] >= -1e-7) and np.all(np.abs(f[:, :2]) <= cfg['friction_coef'] * f[:, 2:3] + 1e-6)
+    # standing still on four feet at the nominal pose
+    q0 = np.array(cfg['init_config'], float)
+    fz = cfg['mass'] * 9.81 / 4
+    ctl, sol, st, iters = g.qp_control(q0, np.zeros(18), [1, 1, 1, 1], q0, np.zeros(18), np.tile([0, 0, fz], 4))
+    assert st[0] == 0 and np.abs(sol[0, :18]).max() < 0.5             # (almost) no acceleration: the weight is carried
+    assert abs(sol[0, 18:].reshape(4, 3)[:, 2].sum() - cfg['mass'] * 9.81) < 1.0
+    assert np.all(ctl[0, 24:].reshape(4, 3)[:, 2] != 0)                # the calf joints work against gravity
