@@ -228,8 +228,9 @@ def main():
     ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps run back to back; the median is reported')
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='instances per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--workload', choices=['B', 'D'], default='B',
-                    help='B (default, the metric\'s configuration): 256 instances/GPU, N=20; D: 512 instances/GPU, N=50, push distribution')
+    ap.add_argument('--workload', choices=['B', 'D', 'E'], default='B',
+                    help='B (default, the metric\'s configuration): 256 instances/GPU, N=20; D: 512 instances/GPU, N=50, push distribution; '
+                         'E: 128 instances/GPU, N=40 (2 s horizon, 232 spline variables) on the LARGE-capacity build')
     ap.add_argument('--closed-loop-steps', type=int, default=20,
                     help='extra, separately timed segment: closed-loop rollouts against the SRBM plant with pushes (0 = skip)')
     ap.add_argument('--gait-steps', type=int, default=30,
@@ -254,9 +255,12 @@ def main():
     from srbm_loader import host
 
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    cfg = host.load_config('a1_configuration' if args.workload == 'B' else 'a1_config_distr_rejection')
-    B = args.batch if args.workload == 'B' else (512 if args.batch == BATCH_PER_GPU else args.batch)
-    make_instance = config_b_instance if args.workload == 'B' else config_d_instance
+    if args.workload == 'E':       # SURVEY.md 8d Config E: the SRBM path at N = 40, dt = 0.05 (the reference's centroidal MPC is dead code)
+        cfg = host.load_config('a1_configuration', num_nodes=40)
+    else:
+        cfg = host.load_config('a1_configuration' if args.workload == 'B' else 'a1_config_distr_rejection')
+    B = args.batch if args.workload == 'B' else ((512 if args.workload == 'D' else 128) if args.batch == BATCH_PER_GPU else args.batch)
+    make_instance = config_d_instance if args.workload == 'D' else config_b_instance
     lo, hi = shard_range(B * world, rank, world)            # this rank's instances of the global batch
     n_inst = B * world
 
@@ -289,7 +293,7 @@ def main():
     states, ees = zip(*[make_instance(cfg, b) for b in range(lo, hi)])
     states, ees = np.array(states), np.array(ees).reshape(hi - lo, 12)
 
-    mpc = host.BatchMPC(cfg, hi - lo, device=local_rank)
+    mpc = host.BatchMPC(cfg, hi - lo, device=local_rank, large=(args.workload == 'E'))     # a 2 s horizon needs 232 spline variables: LARGE build
     mpc.set_state_trajectory_warm_start(states)
     mpc.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
     mpc.create_initial_run(states, ees)                       # 10 cold-start solves (set-up, untimed)
@@ -374,7 +378,7 @@ def main():
     cl_stats = None
     if args.closed_loop_steps > 0:
         SUB = 10
-        cl = host.BatchMPC(cfg, hi - lo, device=local_rank)
+        cl = host.BatchMPC(cfg, hi - lo, device=local_rank, large=mpc.large)
         cl.set_state_trajectory_warm_start(states)
         cl.create_initial_run(states, ees)
         cl.plant_set_state(states)
@@ -429,7 +433,7 @@ def main():
         exec_tflops = mfma_per_launch * MFMA_FLOP / k3_avg_s / 1e12 if k3_avg_s > 0 else 0.0
         traffic, pmc = pmc_traffic(args.steps) if args.workload == 'B' else (None, None)
         roof = {'bound': 'mfma', 'limiter': 'latency of dependent chains (1 workgroup of 8 waves per CU, no HBM or matrix-pipe saturation)',
-                'kernel': 'srbm_rti_fused' if cfg['num_nodes'] <= 22 else 'srbm_rti_fused_long',
+                'kernel': ('srbm_rti_fused' if cfg['num_nodes'] <= 22 else 'srbm_rti_fused_long') + (' (LARGE build)' if mpc.large else ''),
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_PEAK_TFLOPS,
                 'achieved_is': 'ALGORITHMIC flops (SURVEY.md 8d formula at the sizes and IPM iteration counts executed) / measured launch time',
                 'traffic': traffic, 'avg_launch_ms': k3_avg_s * 1e3, 'launches_timed': k3_launches,
@@ -449,7 +453,9 @@ def main():
             'config': {'workload': ('Config B: %d A1 SRBM MPC instances per GPU, N=20, dt=0.05, a1_configuration.yaml values, '
                                     '10 cold-start solves then open-loop RTI steps (state := node 1)' % B) if args.workload == 'B' else
                                    ('Config D: %d A1 SRBM MPC instances per GPU, N=50, dt=0.02, a1_config_distr_rejection.yaml values, push '
-                                    'distribution on the initial momentum, 10 cold-start solves then open-loop RTI steps' % B),
+                                    'distribution on the initial momentum, 10 cold-start solves then open-loop RTI steps' % B) if args.workload == 'D' else
+                                   ('Config E (SRBM stand-in for the dead centroidal MPC, no reference parity beyond the SRBM restatement): %d instances per GPU, '
+                                    'N=40, dt=0.05, a1_configuration.yaml values, LARGE-capacity build (normal matrix in L2)' % B),
                        'batch_per_gpu': B, 'global_batch': n_inst, 'num_nodes': cfg['num_nodes'], 'parallelism': 'instances sharded x%d' % world,
                        'records_gathered': int(allrec.shape[0]), 'record_doubles': LD,
                        'all_solved': bool(q[2] == 0 and q[0] == 0), 'statuses_last_step': {int(k): int(v) for k, v in zip(*np.unique(status_all, return_counts=True))},

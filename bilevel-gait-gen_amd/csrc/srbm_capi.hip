@@ -14,6 +14,11 @@
 #include "srbm_wbc.hiph"
 #include "../../include/srbm_rti.h"
 
+#ifdef SRBM_LARGE
+#define SRBM_DYN_LDS(T) sizeof(T)        /* LARGE build: the working sets of kernels 1, 2, 4 exceed 64 KB of static LDS */
+#else
+#define SRBM_DYN_LDS(T) 0
+#endif
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return -1; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
@@ -332,14 +337,14 @@ static void inv3(const double* m, double* r) {
 static int launch_step(srbm_batch* h) {
     if (upload_params(h)) return -1;
     const int B = h->batch;
-    hipLaunchKernelGGL(srbm_k1_assemble, dim3(B), dim3(K1_THREADS), 0, h->stream, h->dp, h->insts, h->works, h->d_state, h->d_time, h->d_ee);
-    hipLaunchKernelGGL(srbm_k2_condense, dim3(B), dim3(K2_THREADS), 0, h->stream, h->dp, h->insts, h->works);
+    hipLaunchKernelGGL(srbm_k1_assemble, dim3(B), dim3(K1_THREADS), SRBM_DYN_LDS(K1Shared), h->stream, h->dp, h->insts, h->works, h->d_state, h->d_time, h->d_ee);
+    hipLaunchKernelGGL(srbm_k2_condense, dim3(B), dim3(K2_THREADS), SRBM_DYN_LDS(K2Shared), h->stream, h->dp, h->insts, h->works);
     const bool tm = h->timing && h->ev_used < h->ev_start.size();
     if (tm) HIPCHK(hipEventRecord(h->ev_start[h->ev_used], h->stream));
     if (h->hp.N <= K3_SHORT_N) hipLaunchKernelGGL(srbm_k3_ipm, dim3(B), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works);
     else hipLaunchKernelGGL(srbm_k3_ipm_long, dim3(B), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works);
     if (tm) { HIPCHK(hipEventRecord(h->ev_stop[h->ev_used], h->stream)); h->ev_steps[h->ev_used] = 1; h->ev_used++; }
-    hipLaunchKernelGGL(srbm_k4_update, dim3(B), dim3(K4_THREADS), 0, h->stream, h->dp, h->insts, h->works);
+    hipLaunchKernelGGL(srbm_k4_update, dim3(B), dim3(K4_THREADS), SRBM_DYN_LDS(K4Shared), h->stream, h->dp, h->insts, h->works);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -385,7 +390,11 @@ __global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_solve(int n, const do
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
     dn_trtri(M, n);
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
-    dn_solve_inv(0, n, (int)(xv - dbg_smem2), (int)(tv - dbg_smem2));
+    dn_solve_inv(0, n, (int)(xv - dbg_smem2), (int)(tv - dbg_smem2)
+#ifdef SRBM_LARGE
+                 , M
+#endif
+    );
     const long long t2 = (long long)__builtin_amdgcn_s_memtime();
     for (int e = threadIdx.x; e < n; e += DN_THREADS) xout[(size_t)blockIdx.x * n + e] = xv[e];
     for (int e = threadIdx.x; e < np; e += DN_THREADS) Xout[(size_t)blockIdx.x * np + e] = M[e];
@@ -410,6 +419,9 @@ __global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_cholesky(int n, const
 }
 /* unit-test hook: x = M^-1 rhs through Cholesky + explicit inverse of the factor; X_packed = L^-1; ticks[2*count] */
 int srbm_debug_solve(int n, int count, const double* M_packed, const double* rhs, double* x, double* X_packed, int* ticks) {
+#ifdef SRBM_LARGE
+    return fail("srbm_debug_solve: the unit-test hooks of the dense blocks exist in the standard build only");
+#endif
     if (n <= 0 || n > SRBM_NUMAX || count <= 0 || !M_packed || !rhs || !x || !X_packed || !ticks) return fail("bad arguments");
     const size_t np = (size_t)n * (n + 1) / 2, bytes = np * count * sizeof(double), vb = (size_t)n * count * sizeof(double);
     double *dM = nullptr, *dX = nullptr, *dr = nullptr, *dx = nullptr; int* dt = nullptr;
@@ -429,6 +441,9 @@ int srbm_debug_solve(int n, int count, const double* M_packed, const double* rhs
     return 0;
 }
 int srbm_debug_cholesky(int n, int count, const double* M_packed, double* L_packed, int* nreg) {
+#ifdef SRBM_LARGE
+    return fail("srbm_debug_cholesky: the unit-test hooks of the dense blocks exist in the standard build only");
+#endif
     if (n <= 0 || n > SRBM_NUMAX || count <= 0 || !M_packed || !L_packed || !nreg) return fail("bad arguments");
     const size_t np = (size_t)n * (n + 1) / 2, bytes = np * count * sizeof(double);
     double *dM = nullptr, *dL = nullptr; int* dr = nullptr;
@@ -486,6 +501,12 @@ static int alloc_batch(srbm_batch* h, hipStream_t borrowed_stream) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_rti_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_rti_fused_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_normal_matrix), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
+#ifdef SRBM_LARGE
+    static_assert(sizeof(K1Shared) <= 160 * 1024 && sizeof(K2Shared) <= 160 * 1024 && sizeof(K4Shared) <= 160 * 1024, "working sets fit the LDS of a CU");
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k1_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(K1Shared)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k2_condense), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(K2Shared)));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k4_update), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(K4Shared)));
+#endif
     h->params_dirty = true;
     return 0;
 }
@@ -556,6 +577,7 @@ int srbm_batch_clone(const srbm_batch* src, srbm_batch** out) {
     *out = h;
     return 0;
 }
+int srbm_get_capacity(int* cap4) { if (!cap4) return fail("bad arguments"); cap4[0] = SRBM_NMAX; cap4[1] = SRBM_NUMAX; cap4[2] = SRBM_NSMAX; cap4[3] = SRBM_KMAX; return 0; }
 int srbm_batch_size(const srbm_batch* h) { return h ? h->batch : -1; }
 int srbm_num_nodes(const srbm_batch* h) { return h ? h->hp.N : -1; }
 

@@ -11,10 +11,21 @@
 #include <stdint.h>
 
 #define SRBM_NEE 4
-#define SRBM_NMAX 50          /* horizon nodes (reference configs use 10 / 20 / 50) */
 #define SRBM_KMAX 32          /* knots per foot inside the horizon window */
+#ifdef SRBM_LARGE
+/* The LARGE build of the same sources (libsrbm_rti_large.so): the reference's own limit of 101 trajectory nodes
+   (mpc/include/trajectory.h:165-166), up to 240 spline variables and 20 stance phases in the window -- N = 40 at dt = 0.05 (2 s
+   horizon: 232 variables, 160 force samples) and the short-phase schedules the gait LP may produce (MIN_TIME 0.2,
+   mpc/gait_optimizer.cpp:412).  The packed normal matrix (231 KB at n_u = 240) no longer fits the 160 KB of LDS beside the iterates: it lives in the work record (L2 / Infinity
+   Cache), the tiles still in the accumulator registers during the factorisation.  Same algorithm, same results, slower. */
+#define SRBM_NMAX 100
+#define SRBM_NUMAX 240
+#define SRBM_NSMAX 200
+#else
+#define SRBM_NMAX 50          /* horizon nodes (reference configs use 10 / 20 / 50) */
 #define SRBM_NUMAX 160        /* spline (input) variables */
 #define SRBM_NSMAX 120        /* force samples: FB_PER_FORCE(10) x stance phases in the window */
+#endif
 #define SRBM_NEEROW (2 * (SRBM_NMAX - 3))          /* dense state rows: (node 4..N) x (x,y) */
 #define SRBM_MIMAX (6 * SRBM_NSMAX + 16 * (SRBM_NMAX - 3))
 #define SRBM_NXMAX ((SRBM_NMAX + 1) * 12 + SRBM_NUMAX)
@@ -116,6 +127,9 @@ typedef struct SrbmWork {
     double x[SRBM_NXMAX];                         /* prev_qp_sol after the line search */
     double z[SRBM_MMAX];                          /* dual vector in the reference's row order */
     double s[SRBM_MMAX];
+#ifdef SRBM_LARGE
+    double Mg[SRBM_HPACK];                        /* LARGE build: the normal matrix / its factor / the inverse of the factor of the IPM (in LDS in the standard build) */
+#endif
     double Ms[SRBM_HPACK];                        /* gait step: H + G' diag(lambda/s) G of the last solution (srbm_k3_normal_matrix) */
     double w0[SRBM_MIMAX];                        /* IPM: unit weight of the row/cost-scaled problem, e_r^2 / c (kernel 3 scratch) */
     double prof2[64];                             /* diagnostic builds only: fine-grained stamps (K3_FINE) */

@@ -13,6 +13,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SRBM_RTI_LIB', os.path.join(HERE, 'libsrbm_rti.so'))   # override: A/B builds of scripts/dev_ab.py
+# the LARGE-capacity build of the same sources (N <= 100, n_u <= 240, csrc/srbm_types.h): same C-ABI, slower (normal matrix in L2)
+LIB_PATH_LARGE = os.environ.get('SRBM_RTI_LIB_LARGE', os.path.join(HERE, 'libsrbm_rti_large.so'))
 CONFIG_DIR = os.path.join(HERE, 'configs')
 
 _dp = C.POINTER(C.c_double)
@@ -89,20 +91,23 @@ def build(force=False):
     return LIB_PATH
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError('libsrbm_rti.so is not built (run __graft_entry__.build()); there is no CPU fallback')
-        L = C.CDLL(LIB_PATH)
+def lib(large=False):
+    path = LIB_PATH_LARGE if large else LIB_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
+            raise RuntimeError('%s is not built (run __graft_entry__.build()); there is no CPU fallback' % os.path.basename(path))
+        L = C.CDLL(path)
         L.srbm_last_error.restype = C.c_char_p
         L.srbm_stream.restype = C.c_void_p
         L.srbm_bytes_per_instance.restype = C.c_long
-        _lib = L
-    return _lib
+        cap = (C.c_int * 4)()
+        L.srbm_get_capacity(cap)
+        L.capacity = dict(N=cap[0], nu=cap[1], samples=cap[2], knots=cap[3])
+        _libs[path] = L
+    return _libs[path]
 
 
 def load_config(name='a1_configuration', **overrides):
@@ -166,11 +171,14 @@ def manifold_to_tangent(s13):
 class BatchMPC:
     """batch x mpc::MPCSingleRigidBody on one MI355X."""
 
-    def __init__(self, cfg, batch, device=0):
-        self.L = lib()
+    def __init__(self, cfg, batch, device=0, large=None):
+        self.N = int(cfg['num_nodes'])
+        # horizons beyond the standard build's 50 nodes (or an explicit request) go to the LARGE-capacity build
+        self.large = bool(cfg.get('large', self.N > lib().capacity['N'])) if large is None else bool(large)
+        self.L = lib(self.large)
+        self.NUMAX, self.NSMAX = self.L.capacity['nu'], self.L.capacity['samples']
         self.cfg = cfg
         self.batch = int(batch)
-        self.N = int(cfg['num_nodes'])
         info = MPCInfo()
         info.num_nodes = self.N
         info.integrator_dt = cfg['integrator_dt']
@@ -226,7 +234,7 @@ class BatchMPC:
     def clone(self):
         """MPC copy constructor (mpc.cpp:1133-1181): a deep copy with its own stream and device buffers"""
         c = object.__new__(BatchMPC)
-        c.L, c.cfg, c.batch, c.N = self.L, self.cfg, self.batch, self.N
+        c.L, c.cfg, c.batch, c.N, c.large, c.NUMAX, c.NSMAX = self.L, self.cfg, self.batch, self.N, self.large, self.NUMAX, self.NSMAX
         c.h = C.c_void_p()
         self._chk(self.L.srbm_batch_clone(self.h, C.byref(c.h)))
         return c
@@ -478,19 +486,19 @@ class BatchMPC:
         return a
 
     def qp_solution(self):
-        ld = (self.N + 1) * 12 + 160
+        ld = (self.N + 1) * 12 + self.NUMAX
         a = np.zeros((self.batch, ld))
         self._chk(self.L.srbm_get_qp_solution(self.h, _d(a), ld))
         return a
 
     def raw_qp_minimiser(self):
-        ld = (self.N + 1) * 12 + 160
+        ld = (self.N + 1) * 12 + self.NUMAX
         a = np.zeros((self.batch, ld))
         self._chk(self.L.srbm_get_raw_qp_minimiser(self.h, _d(a), ld))
         return a
 
     def dual_solution(self):
-        ld = (self.N + 1) * 12 + 6 * 120 + 16 * (self.N - 3) + 16
+        ld = (self.N + 1) * 12 + 6 * self.NSMAX + 16 * (self.N - 3) + 16
         z = np.zeros((self.batch, ld)); s = np.zeros((self.batch, ld))
         self._chk(self.L.srbm_get_dual_solution(self.h, _d(z), _d(s), ld))
         return z, s
@@ -547,7 +555,7 @@ class BatchGaitOptimizer:
 
     def sensitivity(self):
         m = self.mpc
-        ld = (m.N + 1) * 12 + 160 + 6 * 120 + 16 * (m.N - 3) + (m.N + 1) * 12 + 16
+        ld = (m.N + 1) * 12 + m.NUMAX + 6 * m.NSMAX + 16 * (m.N - 3) + (m.N + 1) * 12 + 16
         d = np.zeros((m.batch, ld))
         m._chk(self.L.srbm_gait_get_sensitivity(self.g, _d(d), ld))
         return d

@@ -41,6 +41,11 @@ const char* srbm_last_error(void);
  * device buffers and carries the complete state of `src` (parameters, costs, tolerances, trajectories, last QP, plant). */
 int srbm_batch_clone(const srbm_batch* src, srbm_batch** out);
 int srbm_batch_size(const srbm_batch* h);
+/* capacities of this build: cap4 = {max horizon nodes N, max spline variables n_u, max force samples, max knots per foot}.
+ * libsrbm_rti.so: {50, 160, 120, 32}, the configurations the reference ships (its normal matrix lives in LDS);
+ * libsrbm_rti_large.so (same sources, -DSRBM_LARGE): {100, 240, 200, 32}, the reference's own limit of 101 trajectory nodes
+ * (mpc/include/trajectory.h:165-166); same C-ABI, same results, slower (normal matrix in L2). */
+int srbm_get_capacity(int* cap4);
 int srbm_num_nodes(const srbm_batch* h);
 
 /* MPC::AddQuadraticTrackingCost (mpc/mpc.cpp:533-540): Q 12x12 row-major, state_des in tangent coordinates (12) */
