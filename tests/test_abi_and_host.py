@@ -24,11 +24,17 @@ def declared_symbols():
 
 
 def test_library_exports_every_declared_symbol(libpath):
-    L = ctypes.CDLL(libpath)
     names = declared_symbols()
-    assert len(names) >= 20
-    for n in names:
-        assert hasattr(L, n), n
+    assert len(names) >= 60
+    for path in (libpath, host.LIB_PATH_LARGE):        # the standard and the LARGE-capacity build carry the same C-ABI
+        L = ctypes.CDLL(path)
+        for n in names:
+            assert hasattr(L, n), (os.path.basename(path), n)
+    cap = (ctypes.c_int * 4)()
+    ctypes.CDLL(libpath).srbm_get_capacity(cap)
+    assert list(cap) == [50, 160, 120, 32]
+    ctypes.CDLL(host.LIB_PATH_LARGE).srbm_get_capacity(cap)
+    assert list(cap) == [100, 240, 200, 32]
 
 
 def test_code_object_is_gfx950(libpath):
