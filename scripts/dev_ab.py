@@ -17,11 +17,12 @@ if len(sys.argv) > 1 and sys.argv[1] == '--child':
         states, ees = zip(*[bench.config_d_instance(cfg, b) for b in range(B)])
     states, ees = np.array(states), np.array(ees).reshape(B, 12)
     g = host.BatchMPC(cfg, B); g.set_state_trajectory_warm_start(states)
+    if 'AB_TOL' in os.environ: g.set_solver_tolerances(float(os.environ['AB_TOL']), float(os.environ['AB_TOL']), 1e-10, 200)
     for _ in range(10): g.create_initial_run(states, ees)
     g.rti_advance(0, 5); g.synchronize()
     t0 = time.perf_counter(); g.rti_advance(5, 40); g.synchronize(); t1 = time.perf_counter()
     st = g.status()[0]; x = g.qp_solution()
-    print('%-40s %.3f ms/step  iters %.2f  statuses %s  checksum %.17g' % (os.path.basename(os.environ['SRBM_RTI_LIB']), (t1 - t0) / 40 * 1e3,
+    print('%-40s tol %s  %.3f ms/step  iters %.2f  statuses %s  checksum %.17g' % (os.path.basename(os.environ['SRBM_RTI_LIB']), os.environ.get('AB_TOL', 'default'), (t1 - t0) / 40 * 1e3,
           g.stats()[:, 4].mean(), dict(zip(*np.unique(st, return_counts=True))), float(np.nansum(x * np.cos(np.arange(x.size).reshape(x.shape))))))
 else:
     for lib in sys.argv[1:]:

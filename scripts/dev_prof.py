@@ -9,7 +9,7 @@ cfg = host.load_config(sys.argv[1] if len(sys.argv) > 1 else 'a1_configuration')
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 s0 = np.array(cfg['srb_init'], float)
 ee = np.array([[0.2, 0.2, 0], [0.2, -0.2, 0], [-0.2, 0.2, 0], [-0.2, -0.2, 0]], float)
-gb = host.BatchMPC(cfg, B); gb.set_state_trajectory_warm_start(s0); gb.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+gb = host.BatchMPC(cfg, B); gb.set_state_trajectory_warm_start(s0)
 gb.create_initial_run(s0, ee)
 gb.rti_advance(0, 4); gb.synchronize()
 out = np.zeros(16)
@@ -22,8 +22,11 @@ for n, v in zip(names, out):
 
 out2 = np.zeros(64)
 gb.L.srbm_debug_get_profile2(gb.h, 0, out2.ctypes.data_as(C.POINTER(C.c_double)))
-names2 = {0: 'other->eval', 1: 'eval: force samples', 2: 'eval: dense rows', 3: 'other->gt', 4: 'gt: cs', 5: 'gt: dense rows', 6: 'gt: sparse gather', 7: 'other->M', 8: 'M force blocks', 9: 'M pos blocks', 10: 'M dense + factor + invert', 20: '  tiles <- LDS', 21: '  cholesky', 22: '  invert diag blocks', 23: '  trtri', 24: '  rank-2 update (MFMA)'}
+names2 = {0: 'other->eval', 1: 'eval: force samples', 2: 'eval: dense rows', 3: 'other->gt', 4: 'gt: cs', 5: 'gt: dense rows', 6: 'gt: sparse gather', 7: 'other->M', 8: 'M force blocks', 9: 'M pos blocks', 10: 'M dense + factor + invert', 20: '  tiles <- LDS', 21: '  cholesky', 22: '  invert diag blocks', 23: '  trtri', 24: '  rank-2 update (MFMA)',
+          30: 'dir: (other)', 31: 'dir: row rhs', 33: 'dir: col rhs (after G\' pass)', 34: 'dir: tri solves', 35: 'dir: row products (after G pass)',
+          36: 'ref: e2 + row write', 32: 'ref: (G\' pass, in 4-6)', 37: 'ref: H du (L2)', 38: 'ref: e1 + err reductions', 39: 'ref: corr rhs (after G\' pass)', 40: 'ref: tri solves', 41: 'ref: row products + update', 42: 'ref: exit',
+          43: 'ds + step length', 44: 'gz: targets + row write', 45: 'gz: col rhs (after G\' pass)', 46: 'gz: tri solves', 47: 'gz: row products + step'}
 print('fine stamps (accumulated over all RTI steps of this process; shares of their sum):')
-tot2 = out2.sum()
+out2[7] = 0; tot2 = out2.sum()
 for k, n in names2.items():
     print('%-28s %12.0f %5.1f%%' % (n, out2[k], 100 * out2[k] / tot2))
