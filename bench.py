@@ -235,6 +235,8 @@ def main():
                     help='extra, separately timed segment: closed-loop rollouts against the SRBM plant with pushes (0 = skip)')
     ap.add_argument('--gait-steps', type=int, default=30,
                     help='extra, separately timed segment (Config C): controller loop with the bilevel (gait) step every 5th iteration (0 = skip)')
+    ap.add_argument('--wbc-ticks', type=int, default=20,
+                    help='fourth segment: 1 kHz control ticks (targets from the trajectory by IK + whole-body QP) of the batch; 0 skips it')
     ap.add_argument('--dry-run', action='store_true', help='CPU rehearsal of the launcher / sharding / gather path (gloo, no HIP call)')
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.repeats < 1:
@@ -410,6 +412,39 @@ def main():
                     'err_bits_all_steps': int(np.bitwise_or.reduce(accc[:, 0])), 'not_solved_all_steps': int(accc[:, 2].sum()),
                     'plant_finite': bool(np.all(np.isfinite(cl.plant_state())))}
         del cl
+    # ---- fourth segment: the 1 kHz step downstream of the MPC for the whole batch: MPCController::GetTargetsFromTraj (two IK
+    # solves per instance) then QPControl::ComputeControlAction (rigid-body dynamics + the whole-body QP), through the host-pointer entries ----
+    wbc_stats = None
+    if args.wbc_ticks > 0 and args.workload == 'B' and 'init_config' in cfg:
+        nb = hi - lo
+        t0w = mpc.get_trajectory(0, 1)[0].init_time
+        q_des = np.tile(np.array(cfg['init_config'], float), (nb, 1))
+        q_des, v_des, f_des, st_t = mpc.get_targets_from_traj(t0w, q_des)           # warm-up tick (also the IK guess of the first timed one)
+        rngw = np.random.default_rng(4242 + lo)
+        bad_t = bad_q = 0; qp_it = []
+        torch.cuda.synchronize()
+        tw = time.perf_counter(); t_targets = 0.0
+        for k in range(args.wbc_ticks):
+            tk = t0w + 1e-3 * (k + 1)
+            ta = time.perf_counter()
+            q_des, v_des, f_des, st_t = mpc.get_targets_from_traj(tk, q_des)
+            t_targets += time.perf_counter() - ta
+            _, _, con = mpc.eval_trajectory(tk)
+            fd = np.zeros((nb, 12))
+            for b in range(nb):                                                        # force_target_: 3 per foot in contact, stacked in foot order
+                sel = f_des[b][con[b] > 0].reshape(-1)
+                fd[b, :sel.size] = sel
+            q_meas = q_des.copy(); q_meas[:, 7:] += rngw.normal(size=(nb, 12)) * 0.01  # "measured" state: the target with a tracking error
+            v_meas = v_des + rngw.normal(size=(nb, 18)) * 0.01
+            ctl, sol, st_q, it_q = mpc.qp_control(q_meas, v_meas, con, q_des, v_des, fd)
+            bad_t += int((st_t != 0).sum()); bad_q += int((st_q > 1).sum()); qp_it.append(it_q.mean())
+        el_w = max_over_ranks(time.perf_counter() - tw)
+        wbc_stats = {'workload': '1 kHz control ticks downstream of the MPC for the %d instances of the batch: GetTargetsFromTraj (linear state interpolation, '
+                                 'two IK solves, force splines) + QPControl::ComputeControlAction (dynamics by recursive Newton-Euler, whole-body QP), '
+                                 'host-pointer entries (PCIe copies and the host-side stacking of the contact forces included)' % nb,
+                     'ticks': args.wbc_ticks, 'control_actions_per_s': n_inst * args.wbc_ticks / el_w, 'ms_per_tick_of_the_batch': 1e3 * el_w / args.wbc_ticks,
+                     'ms_per_tick_targets_only': 1e3 * t_targets / args.wbc_ticks,
+                     'targets_not_ok': bad_t, 'qp_not_solved': bad_q, 'mean_qp_ipm_iterations': float(np.mean(qp_it)), 'finite': bool(np.all(np.isfinite(ctl)))}
     value = n_inst * args.steps / elapsed
 
     # quality of ALL timed solves of this rank (sticky accumulators), reduced over the ranks
@@ -468,6 +503,8 @@ def main():
             out['gait'] = gait_stats
         if cl_stats is not None:
             out['closed_loop'] = cl_stats
+        if wbc_stats is not None:
+            out['wbc'] = wbc_stats
         if world == 1 and not args.no_cpu_baseline and args.workload == 'B':
             try:
                 out['cpu_baseline'] = cpu_baseline(cfg)

@@ -253,22 +253,26 @@ __global__ void srbm_k_forward_kinematics(const SrbmParams* __restrict__ Pp, con
     if (b >= Pp->batch) return;
     ik_forward_kinematics(srbm_legs(*Pp), q + (size_t)b * 19, ee + (size_t)b * 12);
 }
-__global__ void srbm_k_inverse_kinematics(const SrbmParams* __restrict__ Pp, const double* __restrict__ state, const double* __restrict__ ee,
+// One wave per instance (srbm_ik.hiph): every lane runs the same chain on the same data, the small vectors live in LDS, lane 0 stores.
+#define SRBM_IK_THREADS 64
+__global__ __launch_bounds__(SRBM_IK_THREADS) void srbm_k_inverse_kinematics(const SrbmParams* __restrict__ Pp, const double* __restrict__ state, const double* __restrict__ ee,
                                           const double* __restrict__ q_guess, double* __restrict__ q_out, int* __restrict__ iters, int* __restrict__ status) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= Pp->batch) return;
-    double q[19];
-    for (int i = 0; i < 19; i++) q[i] = q_guess[(size_t)b * 19 + i];
-    int it[4];
-    status[b] = ik_inverse_kinematics(srbm_legs(*Pp), state + (size_t)b * 13, ee + (size_t)b * 12, q, it);
-    for (int i = 0; i < 19; i++) q_out[(size_t)b * 19 + i] = q[i];
-    for (int i = 0; i < 4; i++) iters[b * 4 + i] = it[i];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ double q[19], s13[13], e12[12];
+    __shared__ int it[4];
+    if (lane < 19) q[lane] = q_guess[(size_t)b * 19 + lane];
+    if (lane < 13) s13[lane] = state[(size_t)b * 13 + lane];
+    if (lane < 12) e12[lane] = ee[(size_t)b * 12 + lane];
+    __syncthreads();
+    const int failed = ik_inverse_kinematics(srbm_legs(*Pp), s13, e12, q, it);
+    __syncthreads();
+    if (lane < 19) q_out[(size_t)b * 19 + lane] = q[lane];
+    if (lane < 4) iters[b * 4 + lane] = it[lane];
+    if (lane == 0) status[b] = failed;
 }
-// MPCController::GetTargetsFromTraj (controllers/mpc_controller.cpp:414-511) on the current trajectory of every instance
-__global__ void srbm_k_targets_from_traj(const SrbmParams* __restrict__ Pp, const SrbmInst* __restrict__ insts, const double* __restrict__ time_in,
+__global__ __launch_bounds__(SRBM_IK_THREADS) void srbm_k_targets_from_traj(const SrbmParams* __restrict__ Pp, const SrbmInst* __restrict__ insts, const double* __restrict__ time_in,
                                          double* __restrict__ q_des, double* __restrict__ v_des, double* __restrict__ force_des, int* __restrict__ status) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= Pp->batch) return;
+    const int b = blockIdx.x, lane = threadIdx.x;
     const SrbmParams& P = *Pp;
     const SrbmInst& I = insts[b];
     const int N = P.N;
@@ -276,46 +280,58 @@ __global__ void srbm_k_targets_from_traj(const SrbmParams* __restrict__ Pp, cons
     double time = time_in[b];
     if (time < t0) time = t0;
     const int node = (int)ceil((time - t0) / dt);
-    int st = 0, err = 0;
-    if (node < 0 || node + 1 > N) { status[b] = 2; return; }          // GetState(node + 1) beyond the horizon: the reference's vector access throws
+    if (node < 0 || node + 1 > N) { if (lane == 0) status[b] = 2; return; }          // GetState(node + 1) beyond the horizon: the reference's vector access throws
+    __shared__ double s1[13], s2[13], ee1[12], ee2[12], F[12], q[19], q2[19];
+    __shared__ int it[4], flags[2];
     auto T = [&](int k) { return t0 + dt * k; };
-    double s1[13], s2[13];
     const double* S = I.states;
-    if (node > 0) {
-        const double a = 1 - (T(node) - time) / (T(node) - T(node - 1));
-        for (int i = 0; i < 13; i++) s1[i] = (S[node * 13 + i] - S[(node - 1) * 13 + i]) * a + S[(node - 1) * 13 + i];
-        if (time + dt < T(node)) st = 2;                              // "bad interp."
-        const double c = 1 - (T(node + 1) - (time + dt)) / (T(node + 1) - T(node));
-        for (int i = 0; i < 13; i++) s2[i] = (S[(node + 1) * 13 + i] - S[node * 13 + i]) * c + S[node * 13 + i];
-    } else {
-        const double a = 1 - (T(1) - time) / (T(1) - T(0));
-        const double c = 1 - (T(1) - (time + dt)) / (T(1) - T(0));
-        for (int i = 0; i < 13; i++) { s1[i] = (S[13 + i] - S[i]) * a + S[i]; s2[i] = (S[13 + i] - S[i]) * c + S[i]; }
+    if (lane < 2) flags[lane] = 0;
+    __syncthreads();
+    if (lane < 13) {
+        const int i = lane;
+        if (node > 0) {
+            const double a = 1 - (T(node) - time) / (T(node) - T(node - 1));
+            s1[i] = (S[node * 13 + i] - S[(node - 1) * 13 + i]) * a + S[(node - 1) * 13 + i];
+            const double c = 1 - (T(node + 1) - (time + dt)) / (T(node + 1) - T(node));
+            s2[i] = (S[(node + 1) * 13 + i] - S[node * 13 + i]) * c + S[node * 13 + i];
+        } else {
+            const double a = 1 - (T(1) - time) / (T(1) - T(0));
+            const double c = 1 - (T(1) - (time + dt)) / (T(1) - T(0));
+            s1[i] = (S[13 + i] - S[i]) * a + S[i]; s2[i] = (S[13 + i] - S[i]) * c + S[i];
+        }
     }
-    double ee1[12], ee2[12], F[12];
-    for (int ee = 0; ee < SRBM_NEE; ee++) {
+    if (lane >= 16 && lane < 16 + SRBM_NEE) {        // the splines of one foot per lane
+        const int ee = lane - 16;
+        int err = 0;
         const FootView f{I.knot_t[ee], I.kind[ee], I.nk[ee]};
-        srbm_posxy_value(f, &I.pval[ee][0][0], time, ee1 + 3 * ee, &err);
-        ee1[3 * ee + 2] = srbm_posz_value(f, time, P.swing_height, P.foot_offset, &err);
-        srbm_posxy_value(f, &I.pval[ee][0][0], time + dt, ee2 + 3 * ee, &err);
-        ee2[3 * ee + 2] = srbm_posz_value(f, time + dt, P.swing_height, P.foot_offset, &err);
-        srbm_force_value(f, &I.fval[ee][0][0][0], time, F + 3 * ee, &err);
+        double e1[3], e2[3], ff[3];
+        srbm_posxy_value(f, &I.pval[ee][0][0], time, e1, &err);
+        e1[2] = srbm_posz_value(f, time, P.swing_height, P.foot_offset, &err);
+        srbm_posxy_value(f, &I.pval[ee][0][0], time + dt, e2, &err);
+        e2[2] = srbm_posz_value(f, time + dt, P.swing_height, P.foot_offset, &err);
+        srbm_force_value(f, &I.fval[ee][0][0][0], time, ff, &err);
+        for (int c = 0; c < 3; c++) { ee1[3 * ee + c] = e1[c]; ee2[3 * ee + c] = e2[c]; F[3 * ee + c] = ff[c]; }
+        if (err) atomicOr(&flags[0], 1);
     }
-    if (err) st = 2;
-    double q[19], q2[19];
-    for (int i = 0; i < 19; i++) q[i] = q_des[(size_t)b * 19 + i];
-    int it[4];
+    if (lane >= 32 && lane < 32 + 19) q[lane - 32] = q_des[(size_t)b * 19 + lane - 32];
+    __syncthreads();
+    int st = 0;
+    if (node > 0 && time + dt < T(node)) st = 2;                              // "bad interp."
+    if (flags[0]) st = 2;
     const SrbmLegs& L = srbm_legs(P);
     if (ik_inverse_kinematics(L, s1, ee1, q, it) && st == 0) st = 1;
-    for (int i = 0; i < 19; i++) q2[i] = q[i];
+    __syncthreads();
+    if (lane < 19) q2[lane] = q[lane];
+    __syncthreads();
     if (ik_inverse_kinematics(L, s2, ee2, q2, it) && st == 0) st = 1;
+    __syncthreads();
     double* v = v_des + (size_t)b * 18;
-    for (int i = 0; i < 3; i++) v[i] = s1[3 + i] / P.mass;
-    for (int i = 0; i < 3; i++) v[3 + i] = P.Ir_inv[3 * i] * s1[10] + P.Ir_inv[3 * i + 1] * s1[11] + P.Ir_inv[3 * i + 2] * s1[12];
-    for (int j = 0; j < 12; j++) v[6 + j] = (-q[7 + j] + q2[7 + j]) / dt;
-    for (int i = 0; i < 19; i++) q_des[(size_t)b * 19 + i] = q[i];
-    for (int i = 0; i < 12; i++) force_des[(size_t)b * 12 + i] = F[i];
-    status[b] = st;
+    if (lane < 3) v[lane] = s1[3 + lane] / P.mass;
+    else if (lane < 6) { const int i = lane - 3; v[lane] = P.Ir_inv[3 * i] * s1[10] + P.Ir_inv[3 * i + 1] * s1[11] + P.Ir_inv[3 * i + 2] * s1[12]; }
+    else if (lane < 18) { const int j = lane - 6; v[lane] = (-q[7 + j] + q2[7 + j]) / dt; }
+    if (lane < 19) q_des[(size_t)b * 19 + lane] = q[lane];
+    if (lane < 12) force_des[(size_t)b * 12 + lane] = F[lane];
+    if (lane == 0) status[b] = st;
 }
 
 // ---------------- host helpers ----------------
@@ -1518,7 +1534,7 @@ int srbm_inverse_kinematics(srbm_batch* h, const double* state, const double* ee
     HIPCHK(hipMemcpyAsync(ds, state, sizeof(double) * 13 * B, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(de, ee, sizeof(double) * 12 * B, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(dg, q_guess, sizeof(double) * 19 * B, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(srbm_k_inverse_kinematics, dim3((h->batch + 63) / 64), dim3(64), 0, h->stream, h->dp, ds, de, dg, dq, di, dst);
+    hipLaunchKernelGGL(srbm_k_inverse_kinematics, dim3(h->batch), dim3(SRBM_IK_THREADS), 0, h->stream, h->dp, ds, de, dg, dq, di, dst);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(q_out, dq, sizeof(double) * 19 * B, hipMemcpyDeviceToHost));
@@ -1541,7 +1557,7 @@ int srbm_get_targets_from_traj(srbm_batch* h, const double* time, double* q_des,
     int* dst = reinterpret_cast<int*>(df + 12 * B);
     HIPCHK(hipMemcpyAsync(dt_, time, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(dq, q_des, sizeof(double) * 19 * B, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(srbm_k_targets_from_traj, dim3((h->batch + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts, dt_, dq, dvv, df, dst);
+    hipLaunchKernelGGL(srbm_k_targets_from_traj, dim3(h->batch), dim3(SRBM_IK_THREADS), 0, h->stream, h->dp, h->insts, dt_, dq, dvv, df, dst);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(q_des, dq, sizeof(double) * 19 * B, hipMemcpyDeviceToHost));

@@ -12,7 +12,7 @@ OUT=gpurun_out/prof
 rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="bench.py --no-cpu-baseline --gait-steps 0 --closed-loop-steps 0"
+CMD="bench.py --no-cpu-baseline --gait-steps 0 --closed-loop-steps 0 --wbc-ticks 0"
 python3 $CMD > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err || exit 1
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || exit 1
 pass() {   # name, counters...

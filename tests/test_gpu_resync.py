@@ -17,7 +17,7 @@ import pytest
 
 from oracle_py import OracleMPC, load_config
 from srbm_loader import host
-from bench import config_b_instance, config_c_instance
+from bench import config_b_instance, config_c_instance, config_d_instance
 
 pytestmark = pytest.mark.gpu
 REL_TOL = 1e-4
@@ -223,6 +223,19 @@ def test_config_c_values_at_n20_entrywise():
     r = resync_protocol(cfg, states, ees, steps=12, qp_every=2)
     assert r['worst']['A'] <= 1e-12 and r['worst']['x'] < REL_TOL
     print('resync parity, config C values 64 x 12: worst', r['worst'])
+
+
+def test_config_d_n50_share_entrywise():
+    """BASELINE config 4 (a1_config_distr_rejection.yaml: N = 50, dt = 0.02, pushes on the initial momentum): a 16-instance share of
+    its 512 per GPU over 6 steps, entry-wise as above (the 3-rows-per-thread instance of the solve kernel)"""
+    cfg = load_config('a1_config_distr_rejection')
+    assert cfg['num_nodes'] == 50
+    B = 16
+    states, ees = zip(*[config_d_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees)
+    r = resync_protocol(cfg, states, ees, steps=6, qp_every=2)
+    assert r['worst']['A'] <= 1e-12 and r['worst']['x'] < REL_TOL
+    print('resync parity, config D 16 x 6: alive', r['alive'], 'worst', r['worst'])
 
 
 def test_trajectory_roundtrip_clone_and_evaluation():
