@@ -45,6 +45,8 @@ struct srbm_batch {
     SrbmWbcParams* d_wbc = nullptr;  // whole-body QP model and gains (row f3), set by srbm_set_wbc_model
     void* d_scratch = nullptr;       // staging buffer of the small host->device entry points (grown on demand, never per call)
     size_t scratch_bytes = 0;
+    void* h_stage = nullptr;         // pinned host mirror of d_scratch for the per-tick entries: ONE copy in, ONE copy out per call
+    size_t stage_bytes = 0;
 };
 static int batch_scratch(srbm_batch* h, size_t bytes, void** out) {
     if (bytes > h->scratch_bytes) {
@@ -55,6 +57,18 @@ static int batch_scratch(srbm_batch* h, size_t bytes, void** out) {
         h->scratch_bytes = bytes;
     }
     *out = h->d_scratch;
+    return 0;
+}
+// device scratch + a pinned host buffer of the same size and layout
+static int batch_stage(srbm_batch* h, size_t bytes, void** dev, void** host) {
+    if (batch_scratch(h, bytes, dev)) return -1;
+    if (bytes > h->stage_bytes) {
+        if (h->h_stage) HIPCHK(hipHostFree(h->h_stage));
+        h->h_stage = nullptr; h->stage_bytes = 0;
+        HIPCHK(hipHostMalloc(&h->h_stage, bytes, hipHostMallocDefault));
+        h->stage_bytes = bytes;
+    }
+    *host = h->h_stage;
     return 0;
 }
 
@@ -492,7 +506,7 @@ static void free_batch(srbm_batch* h) {
     (void)hipFree(h->dp); (void)hipFree(h->insts); (void)hipFree(h->works);
     (void)hipFree(h->d_state); (void)hipFree(h->d_time); (void)hipFree(h->d_ee);
     (void)hipFree(h->d_plant); (void)hipFree(h->d_push_time); (void)hipFree(h->d_push_impulse);
-    (void)hipFree(h->d_scratch); (void)hipFree(h->d_wbc);
+    (void)hipFree(h->d_scratch); (void)hipFree(h->d_wbc); (void)hipHostFree(h->h_stage);
     for (auto e : h->ev_start) (void)hipEventDestroy(e);
     for (auto e : h->ev_stop) (void)hipEventDestroy(e);
     if (h->owns_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -1415,21 +1429,25 @@ int srbm_eval_trajectory(srbm_batch* h, const double* time, double* force, doubl
     if (!h || !time) return fail("bad arguments");
     HIPCHK(hipSetDevice(h->device));
     if (upload_params(h)) return -1;
-    const size_t B = h->batch, nf = sizeof(double) * 12 * B;
-    void* dv = nullptr;
-    if (batch_scratch(h, sizeof(double) * B + 2 * nf + sizeof(int) * 4 * B, &dv)) return -1;
+    const size_t B = h->batch, nf = sizeof(double) * 12 * B, total = sizeof(double) * B + 2 * nf + sizeof(int) * 4 * B;
+    void *dv = nullptr, *hv = nullptr;
+    if (batch_stage(h, total, &dv, &hv)) return -1;
     double* d_t = static_cast<double*>(dv);
     double* d_f = d_t + B;
     double* d_p = d_f + 12 * B;
     int* d_c = reinterpret_cast<int*>(d_p + 12 * B);
-    HIPCHK(hipMemcpyAsync(d_t, time, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+    char* hb = static_cast<char*>(hv);
+    memcpy(hb, time, sizeof(double) * B);
+    HIPCHK(hipMemcpyAsync(d_t, hb, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
     const int tot = h->batch * SRBM_NEE;
     hipLaunchKernelGGL(srbm_k_eval_trajectory, dim3((tot + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts, d_t, d_f, d_p, d_c);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(hb + sizeof(double) * B, d_f, total - sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (force) HIPCHK(hipMemcpy(force, d_f, nf, hipMemcpyDeviceToHost));
-    if (pos) HIPCHK(hipMemcpy(pos, d_p, nf, hipMemcpyDeviceToHost));
-    if (in_contact) HIPCHK(hipMemcpy(in_contact, d_c, sizeof(int) * 4 * B, hipMemcpyDeviceToHost));
+    const char* o = hb + sizeof(double) * B;
+    if (force) memcpy(force, o, nf);
+    if (pos) memcpy(pos, o + nf, nf);
+    if (in_contact) memcpy(in_contact, o + 2 * nf, sizeof(int) * 4 * B);
     return 0;
 }
 int srbm_get_ee_box_center(const srbm_batch* h, double* centers) {
@@ -1547,23 +1565,27 @@ int srbm_get_targets_from_traj(srbm_batch* h, const double* time, double* q_des,
     if (need_legs(h)) return -1;
     HIPCHK(hipSetDevice(h->device));
     if (upload_params(h)) return -1;
-    const size_t B = h->batch;
-    void* dv = nullptr;
-    if (batch_scratch(h, sizeof(double) * (1 + 19 + 18 + 12) * B + sizeof(int) * B, &dv)) return -1;
+    const size_t B = h->batch, nin = sizeof(double) * (1 + 19) * B, total = sizeof(double) * (1 + 19 + 18 + 12) * B + sizeof(int) * B;
+    void *dv = nullptr, *hv = nullptr;
+    if (batch_stage(h, total, &dv, &hv)) return -1;
     double* dt_ = static_cast<double*>(dv);
     double* dq = dt_ + B;
     double* dvv = dq + 19 * B;
     double* df = dvv + 18 * B;
     int* dst = reinterpret_cast<int*>(df + 12 * B);
-    HIPCHK(hipMemcpyAsync(dt_, time, sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(dq, q_des, sizeof(double) * 19 * B, hipMemcpyHostToDevice, h->stream));
+    char* hb = static_cast<char*>(hv);
+    memcpy(hb, time, sizeof(double) * B);
+    memcpy(hb + sizeof(double) * B, q_des, sizeof(double) * 19 * B);
+    HIPCHK(hipMemcpyAsync(dv, hb, nin, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(srbm_k_targets_from_traj, dim3(h->batch), dim3(SRBM_IK_THREADS), 0, h->stream, h->dp, h->insts, dt_, dq, dvv, df, dst);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(hb + sizeof(double) * B, dq, total - sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(q_des, dq, sizeof(double) * 19 * B, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(v_des, dvv, sizeof(double) * 18 * B, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(force_des, df, sizeof(double) * 12 * B, hipMemcpyDeviceToHost));
-    if (status) HIPCHK(hipMemcpy(status, dst, sizeof(int) * B, hipMemcpyDeviceToHost));
+    const char* o = hb + sizeof(double) * B;
+    memcpy(q_des, o, sizeof(double) * 19 * B);
+    memcpy(v_des, o + sizeof(double) * 19 * B, sizeof(double) * 18 * B);
+    memcpy(force_des, o + sizeof(double) * 37 * B, sizeof(double) * 12 * B);
+    if (status) memcpy(status, o + sizeof(double) * 49 * B, sizeof(int) * B);
     return 0;
 }
 
@@ -1592,32 +1614,40 @@ int srbm_qp_control(srbm_batch* h, const double* q, const double* v, const int* 
     HIPCHK(hipSetDevice(h->device));
     if (upload_params(h)) return -1;
     const size_t B = h->batch, DUMP = WBC_MMAX * WBC_NMAX + 2 * WBC_MMAX + 2 * WBC_NMAX;
-    void* dv = nullptr;
-    const size_t nd = (19 + 18 + 19 + 18 + 12 + 36 + WBC_NMAX + (qp_dump ? DUMP : 0)) * B;
-    if (batch_scratch(h, sizeof(double) * nd + sizeof(int) * 5 * B, &dv)) return -1;
+    // layout (device = pinned host): inputs [q 19 | v 18 | q_des 19 | v_des 18 | force_des 12] doubles, contact 4 ints (padded to doubles);
+    // outputs [control 36 | qp_sol 30] doubles, status 1 int (padded), then the optional dump
+    const size_t n_in_d = (19 + 18 + 19 + 18 + 12) * B, n_con_d = (4 * B * sizeof(int) + sizeof(double) - 1) / sizeof(double);
+    const size_t n_out_d = (36 + WBC_NMAX) * B, n_st_d = (B * sizeof(int) + sizeof(double) - 1) / sizeof(double);
+    const size_t nd = n_in_d + n_con_d + n_out_d + n_st_d + (qp_dump ? DUMP * B : 0);
+    void *dv = nullptr, *hv = nullptr;
+    if (batch_stage(h, sizeof(double) * nd, &dv, &hv)) return -1;
     double* dq = static_cast<double*>(dv);
     double* dvl = dq + 19 * B;
     double* dqd = dvl + 18 * B;
     double* dvd = dqd + 19 * B;
     double* dfd = dvd + 18 * B;
-    double* dctl = dfd + 12 * B;
+    int* dcon = reinterpret_cast<int*>(dq + n_in_d);
+    double* dctl = dq + n_in_d + n_con_d;
     double* dsol = dctl + 36 * B;
-    double* ddump = qp_dump ? dsol + WBC_NMAX * B : nullptr;
-    int* dcon = reinterpret_cast<int*>(static_cast<double*>(dv) + nd);
-    int* dst = dcon + 4 * B;
-    HIPCHK(hipMemcpyAsync(dq, q, sizeof(double) * 19 * B, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(dvl, v, sizeof(double) * 18 * B, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(dqd, q_des, sizeof(double) * 19 * B, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(dvd, v_des, sizeof(double) * 18 * B, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(dfd, force_des, sizeof(double) * 12 * B, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(dcon, contact, sizeof(int) * 4 * B, hipMemcpyHostToDevice, h->stream));
+    int* dst = reinterpret_cast<int*>(dctl + n_out_d);
+    double* ddump = qp_dump ? dctl + n_out_d + n_st_d : nullptr;
+    double* hb = static_cast<double*>(hv);
+    memcpy(hb, q, sizeof(double) * 19 * B);
+    memcpy(hb + 19 * B, v, sizeof(double) * 18 * B);
+    memcpy(hb + 37 * B, q_des, sizeof(double) * 19 * B);
+    memcpy(hb + 56 * B, v_des, sizeof(double) * 18 * B);
+    memcpy(hb + 74 * B, force_des, sizeof(double) * 12 * B);
+    memcpy(hb + n_in_d, contact, sizeof(int) * 4 * B);
+    HIPCHK(hipMemcpyAsync(dv, hb, sizeof(double) * (n_in_d + n_con_d), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(srbm_k_qp_control, dim3(h->batch), dim3(WBC_THREADS), 0, h->stream, h->dp, h->d_wbc, dq, dvl, dcon, dqd, dvd, dfd, dctl, dsol, dst, ddump);
     HIPCHK(hipGetLastError());
+    double* ho = hb + n_in_d + n_con_d;
+    HIPCHK(hipMemcpyAsync(ho, dctl, sizeof(double) * (nd - n_in_d - n_con_d), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(control, dctl, sizeof(double) * 36 * B, hipMemcpyDeviceToHost));
-    if (qp_sol) HIPCHK(hipMemcpy(qp_sol, dsol, sizeof(double) * WBC_NMAX * B, hipMemcpyDeviceToHost));
-    if (status) HIPCHK(hipMemcpy(status, dst, sizeof(int) * B, hipMemcpyDeviceToHost));
-    if (qp_dump) HIPCHK(hipMemcpy(qp_dump, ddump, sizeof(double) * DUMP * B, hipMemcpyDeviceToHost));
+    memcpy(control, ho, sizeof(double) * 36 * B);
+    if (qp_sol) memcpy(qp_sol, ho + 36 * B, sizeof(double) * WBC_NMAX * B);
+    if (status) memcpy(status, ho + n_out_d, sizeof(int) * B);
+    if (qp_dump) memcpy(qp_dump, ho + n_out_d + n_st_d, sizeof(double) * DUMP * B);
     return 0;
 }
 
