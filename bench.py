@@ -49,7 +49,7 @@ def gather_records(rec, world):
     """all-gather of fixed-size per-instance result records (rows) over the ranks"""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return rec
     out = torch.empty((world * rec.shape[0], rec.shape[1]), dtype=rec.dtype, device=rec.device)
     dist.all_gather_into_tensor(out, rec.contiguous())
@@ -59,7 +59,7 @@ def gather_records(rec, world):
 def max_over_ranks(value):
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return value
     dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
     t = torch.tensor([value], dtype=torch.float64, device=dev)
@@ -289,7 +289,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # SRBM_BENCH_FORCE_DIST=1: initialise the RCCL process group and run every collective of the N > 1 path with a world of one rank
+    # (rehearsal of that path on a one-GPU box)
+    DIST = world > 1 or os.environ.get('SRBM_BENCH_FORCE_DIST') == '1'
+    if DIST:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     states, ees = zip(*[make_instance(cfg, b) for b in range(lo, hi)])
@@ -303,7 +307,7 @@ def main():
     mpc.synchronize()
     LD = mpc.result_record_doubles()                          # status..., primal, dual, contact times (SURVEY.md 8e record)
     rec = torch.zeros((hi - lo, LD), dtype=torch.float64, device='cuda')
-    if world > 1:                                             # first collective outside the timed region (communicator set-up)
+    if DIST:                                             # first collective outside the timed region (communicator set-up)
         gather_records(rec, world)
         torch.cuda.synchronize()
 
@@ -315,7 +319,7 @@ def main():
     first = args.warmup
     allrec = None
     for rep in range(args.repeats):
-        if world > 1:
+        if DIST:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -324,7 +328,7 @@ def main():
         mpc.synchronize()
         allrec = gather_records(rec, world)                   # RCCL all-gather of the solved trajectories (primal + dual + schedule)
         torch.cuda.synchronize()
-        if world > 1:
+        if DIST:
             dist.barrier()
         region_s.append(max_over_ranks(time.perf_counter() - t0))
         first += args.steps
@@ -353,14 +357,14 @@ def main():
         firstg = 6
         n_ls = sum(1 for r in range(firstg, firstg + args.gait_steps) if r % FREQ == 0)
         n_go = sum(1 for r in range(firstg, firstg + args.gait_steps) if (r + 1) % FREQ == 0)
-        if world > 1:
+        if DIST:
             dist.barrier()
         torch.cuda.synchronize()
         tg = time.perf_counter()
         gait.rti_advance(firstg, args.gait_steps, FREQ)
         gm.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if DIST:
             dist.barrier()
         el_g = max_over_ranks(time.perf_counter() - tg)
         stg, _ = gm.status()
@@ -392,14 +396,14 @@ def main():
         cl.closed_loop_advance(0, 2, SUB, True)
         cl.synchronize()
         cl.clear_status_accumulators()
-        if world > 1:
+        if DIST:
             dist.barrier()
         torch.cuda.synchronize()
         tc = time.perf_counter()
         cl.closed_loop_advance(2, args.closed_loop_steps, SUB, True)
         cl.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if DIST:
             dist.barrier()
         el_c = max_over_ranks(time.perf_counter() - tc)
         stc, _ = cl.status()
@@ -450,7 +454,7 @@ def main():
 
     # quality of ALL timed solves of this rank (sticky accumulators), reduced over the ranks
     q = np.array([float(np.bitwise_or.reduce(acc_main[:, 0])), float(acc_main[:, 1].sum()), float(acc_main[:, 2].sum()), float(acc_main[:, 3].sum())])
-    if world > 1:
+    if DIST:
         tq = torch.tensor(q, dtype=torch.float64, device='cuda')
         gl = [torch.zeros_like(tq) for _ in range(world)]
         dist.all_gather(gl, tq)
@@ -512,7 +516,7 @@ def main():
             except Exception as e:            # the GPU line stands on its own
                 out['cpu_baseline'] = {'value': None, 'unit': 'it/s', 'cores': 0, 'kind': 'port', 'sample': 'failed: %s' % e}
         print(json.dumps(out))
-    if world > 1:
+    if DIST:
         dist.barrier()
         dist.destroy_process_group()
 

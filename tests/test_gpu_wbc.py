@@ -16,7 +16,7 @@ import ik_numpy as ik
 import wbc_numpy as wbc
 
 pytestmark = pytest.mark.gpu
-CONTACTS = [[1, 1, 1, 1], [1, 0, 0, 1], [0, 1, 1, 0], [1, 1, 1, 0], [0, 0, 1, 0]]
+CONTACTS = [[1, 1, 1, 1], [1, 0, 0, 1], [0, 1, 1, 0], [1, 1, 1, 0], [0, 0, 1, 0], [0, 0, 0, 0]]
 
 
 def make(B, seed=3):
@@ -41,7 +41,8 @@ def test_assembled_qp_and_solution_match_the_oracle():
     fdes = np.zeros((B, 12))
     for b in range(B):
         nc = contact[b].sum()
-        fdes[b, :3 * nc] = np.tile([1.0, -2.0, cfg['mass'] * 9.81 / nc], nc)
+        if nc:
+            fdes[b, :3 * nc] = np.tile([1.0, -2.0, cfg['mass'] * 9.81 / nc], nc)
     g = host.BatchMPC(cfg, B)
     ctl, sol, st, iters, qp = g.qp_control(q, v, contact, q_des, v_des, fdes, dump=True)
     robot = wbc.Robot(cfg)
