@@ -24,5 +24,8 @@ pass pmc_fetch FETCH_SIZE
 pass pmc_write WRITE_SIZE
 pass pmc_sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
 pass pmc_sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU
+# the control-tick kernels of row f3 (targets from the trajectory, whole-body QP): kernel trace of the bench WITH its fourth segment
+rocprofv3 --kernel-trace --stats -d $OUT/trace_f3 -o trace --output-format csv -- python3 bench.py --no-cpu-baseline --gait-steps 0 --closed-loop-steps 0 > $OUT/bench_f3_under_rocprof.json 2> $OUT/trace_f3.err
+echo "trace_f3 rc=$?" >> $OUT/passes.log
 cat $OUT/passes.log
 find $OUT -name "*.csv" | sort

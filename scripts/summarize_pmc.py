@@ -30,6 +30,20 @@ def bench_line(name):
 
 
 shutil.copy(find('trace', '*kernel_stats.csv'), os.path.join(dst, 'bench_kernel_stats.csv'))
+f3 = find('trace_f3', '*kernel_stats.csv')
+if f3:
+    # control-tick kernels (row f3): average duration per call from the kernel trace, next to the bench's own per-tick figures
+    want = ('srbm_k_targets_from_traj', 'srbm_k_qp_control', 'srbm_k_eval_trajectory')
+    rows3 = [r for r in csv.DictReader(open(f3)) if any(w in r['Name'] for w in want)]
+    b3 = bench_line('bench_f3_under_rocprof.json')
+    with open(os.path.join(dst, 'f3_kernel_stats.txt'), 'w') as fh:
+        fh.write('control-tick kernels of one batch of 256 instances, rocprofv3 --kernel-trace --stats of bench.py (fourth segment):\n')
+        for r in rows3:
+            fh.write('%-28s calls %3s  avg %.3f ms  min %.3f  max %.3f\n' % (r['Name'].split('(')[0], r['Calls'], float(r['AverageNs']) / 1e6, float(r['MinNs']) / 1e6, float(r['MaxNs']) / 1e6))
+        if b3 and 'wbc' in b3:
+            w = b3['wbc']
+            fh.write('bench.py of the same run: %.3f ms per tick (targets %.3f, whole-body QP %.3f through the host-pointer entries), targets not ok %d, QPs not solved %d\n' %
+                     (w['ms_per_tick_of_the_batch'], w['ms_per_tick_targets_only'], w.get('ms_per_tick_qp_control_only', float('nan')), w['targets_not_ok'], w['qp_not_solved']))
 for name in ('bench_unprofiled.json', 'bench_under_rocprof.json'):
     shutil.copy(os.path.join(src, name), os.path.join(dst, name))
 ub, pb = bench_line('bench_unprofiled.json'), bench_line('bench_under_rocprof.json')
