@@ -8,7 +8,7 @@ import bench
 cfg = host.load_config()
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 11
 s0, ee = bench.config_b_instance(cfg, b)
-g = host.BatchMPC(cfg, 1); g.set_state_trajectory_warm_start(s0); g.set_solver_tolerances(1e-13, 1e-13, 1e-10, 200)
+g = host.BatchMPC(cfg, 1); g.set_state_trajectory_warm_start(s0)
 g.create_initial_run(s0, ee)
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 for i in range(nsteps):
