@@ -35,6 +35,7 @@ private:
     std::vector<double> v_;
 };
 inline VectorXd operator*(double a, const VectorXd& x) { VectorXd r(x.size()); for (std::ptrdiff_t i = 0; i < x.size(); i++) r(i) = a * x(i); return r; }
+inline VectorXd operator*(const VectorXd& x, double a) { return a * x; }
 inline VectorXd operator+(const VectorXd& a, const VectorXd& b) { VectorXd r(a.size()); for (std::ptrdiff_t i = 0; i < a.size(); i++) r(i) = a(i) + b(i); return r; }
 inline VectorXd operator-(const VectorXd& a, const VectorXd& b) { VectorXd r(a.size()); for (std::ptrdiff_t i = 0; i < a.size(); i++) r(i) = a(i) - b(i); return r; }
 inline std::ostream& operator<<(std::ostream& os, const VectorXd& x) { for (std::ptrdiff_t i = 0; i < x.size(); i++) os << x(i) << (i + 1 < x.size() ? " " : ""); return os; }

@@ -47,7 +47,7 @@ struct Contact {
     std::vector<int> contact_frames_;
     Contact() = default;
     explicit Contact(int num_contacts) : in_contact_(num_contacts, false), contact_frames_(num_contacts, 0) {}
-    int GetNumContacts() const { return (int)in_contact_.size(); }
+    int GetNumContacts() const { int n = 0; for (const bool c : in_contact_) n += c ? 1 : 0; return n; }      // controllers/controller.cpp:13-22: the feet IN contact
 };
 }  // namespace controller
 

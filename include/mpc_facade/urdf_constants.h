@@ -112,16 +112,21 @@ struct Joint { std::string name, type, parent, child; V3 xyz{}; M3 R = M3::I(); 
 
 }  // namespace urdf_detail
 
-// nominal configuration: [base position (3), base quaternion xyzw (4), joint angles in pinocchio's model order]
-inline srbm_model ModelConstantsFromUrdf(const std::string& urdf_path, const std::vector<double>& nom_config) {
-    using namespace urdf_detail;
+namespace urdf_detail {
+struct Robot {
+    std::map<std::string, Link> links;
+    std::vector<Joint> joints;
+    std::map<std::string, std::vector<const Joint*>> children;
+    std::string root;
+    const Joint* joint(const std::string& name) const { for (const Joint& j : joints) if (j.name == name) return &j; return nullptr; }
+};
+// links (inertial data) and joints (parent, child, origin, axis) of a URDF file; the root is the link that is a parent but nobody's child
+inline void parse(const std::string& urdf_path, Robot& R) {
     std::ifstream f(urdf_path);
     if (!f) throw std::runtime_error("Could not open the URDF: " + urdf_path);
     std::stringstream ss;
     ss << f.rdbuf();
     const std::string text = strip_comments(ss.str());
-    std::map<std::string, Link> links;
-    std::vector<Joint> joints;
     for (const Element& l : elements(text, "link")) {
         Link L;
         const auto inr = elements(l.body, "inertial");
@@ -134,7 +139,7 @@ inline srbm_model ModelConstantsFromUrdf(const std::string& urdf_path, const std
             auto g = [&](const char* k) { return std::atof(attr(it, k, "0").c_str()); };
             L.I = {{{g("ixx"), g("ixy"), g("ixz")}, {g("ixy"), g("iyy"), g("iyz")}, {g("ixz"), g("iyz"), g("izz")}}};
         }
-        links[attr(l.tag, "name")] = L;
+        R.links[attr(l.tag, "name")] = L;
     }
     for (const Element& j : elements(text, "joint")) {
         const auto par = elements(j.body, "parent");
@@ -146,15 +151,26 @@ inline srbm_model ModelConstantsFromUrdf(const std::string& urdf_path, const std
         if (!org.empty()) { J.xyz = vec3(attr(org[0].tag, "xyz")); const V3 r = vec3(attr(org[0].tag, "rpy")); J.R = rpy(r[0], r[1], r[2]); }
         const auto ax = elements(j.body, "axis");
         if (!ax.empty()) J.axis = vec3(attr(ax[0].tag, "xyz"), {1, 0, 0});
-        joints.push_back(J);
+        R.joints.push_back(J);
     }
-    if (links.empty() || joints.empty()) throw std::runtime_error("No links / joints found in the URDF: " + urdf_path);
-    std::map<std::string, std::vector<const Joint*>> children;
+    if (R.links.empty() || R.joints.empty()) throw std::runtime_error("No links / joints found in the URDF: " + urdf_path);
     std::map<std::string, bool> is_child;
-    for (const Joint& j : joints) { children[j.parent].push_back(&j); is_child[j.child] = true; }
-    std::string root;
-    for (const Joint& j : joints) if (!is_child.count(j.parent)) { root = j.parent; break; }      // the link that is a parent but nobody's child
-    if (root.empty()) throw std::runtime_error("The URDF has no root link: " + urdf_path);
+    for (const Joint& j : R.joints) { R.children[j.parent].push_back(&j); is_child[j.child] = true; }
+    for (const Joint& j : R.joints) if (!is_child.count(j.parent)) { R.root = j.parent; break; }
+    if (R.root.empty()) throw std::runtime_error("The URDF has no root link: " + urdf_path);
+}
+}  // namespace urdf_detail
+
+// nominal configuration: [base position (3), base quaternion xyzw (4), joint angles in pinocchio's model order]
+inline srbm_model ModelConstantsFromUrdf(const std::string& urdf_path, const std::vector<double>& nom_config) {
+    using namespace urdf_detail;
+    Robot robot;
+    parse(urdf_path, robot);
+    std::map<std::string, Link>& links = robot.links;
+    std::vector<Joint>& joints = robot.joints;
+    std::map<std::string, std::vector<const Joint*>>& children = robot.children;
+    const std::string root = robot.root;
+    (void)joints;
     // actuated joints in pinocchio's model order: depth first, children in alphabetical order of the child link
     std::vector<std::string> order;
     struct Rec { static void visit(const std::string& link, std::map<std::string, std::vector<const Joint*>>& ch, std::vector<std::string>& ord) {
@@ -207,6 +223,77 @@ inline srbm_model ModelConstantsFromUrdf(const std::string& urdf_path, const std
         out.hip_xy[2 * e] = hips[names[e]][0]; out.hip_xy[2 * e + 1] = hips[names[e]][1];
     }
     return out;
+}
+
+
+// Leg geometry for the kinematics entries (srbm_set_leg_kinematics): per leg FL FR RL RR the origins of the hip joint in the trunk, the
+// thigh joint in the hip, the calf joint in the thigh and the foot frame in the calf (what pinocchio builds its joint placements from).
+// The closed-form kinematics of the library are written for joint axes x, y, y and origins without rotation: anything else is refused.
+inline srbm_leg_kinematics LegKinematicsFromUrdf(const std::string& urdf_path) {
+    using namespace urdf_detail;
+    Robot robot;
+    parse(urdf_path, robot);
+    srbm_leg_kinematics out{};
+    const char* legs[4] = {"FL", "FR", "RL", "RR"};
+    const char* suffix[4] = {"_hip_joint", "_thigh_joint", "_calf_joint", "_foot_fixed"};
+    for (int e = 0; e < 4; e++)
+        for (int k = 0; k < 4; k++) {
+            const Joint* j = robot.joint(std::string(legs[e]) + suffix[k]);
+            if (!j) throw std::runtime_error(std::string("No ") + legs[e] + suffix[k] + " in the URDF.");
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++)
+                if (std::fabs(j->R.m[a][b] - (a == b ? 1.0 : 0.0)) > 1e-12) throw std::runtime_error("Joint origin with a rotation: " + j->name);
+            if (k < 3) {
+                const V3 want = k == 0 ? V3{1, 0, 0} : V3{0, 1, 0};
+                for (int a = 0; a < 3; a++) if (std::fabs(j->axis[a] - want[a]) > 1e-12) throw std::runtime_error("Unexpected joint axis: " + j->name);
+            }
+            for (int a = 0; a < 3; a++) out.origin[e][k][a] = j->xyz[a];
+        }
+    return out;
+}
+
+// Rigid bodies of the whole-body model (srbm_set_wbc_model: body_mass / body_com / body_inertia): the trunk and the three moving links of
+// every leg, every link hanging on a FIXED joint merged into its parent (as pinocchio's URDF parser does): mass, centre of mass and
+// rotational inertia about it, in the frame of the body's joint (trunk: the floating-base frame).  Gains and weights are not touched.
+inline void WbcBodiesFromUrdf(const std::string& urdf_path, srbm_wbc_model* out) {
+    using namespace urdf_detail;
+    Robot robot;
+    parse(urdf_path, robot);
+    struct Part { double m; V3 c; M3 I; };
+    struct Merge { static void go(const Robot& R, const std::string& link, const V3& p, const M3& Rot, std::vector<Part>& parts) {
+        const auto it = R.links.find(link);
+        if (it != R.links.end() && it->second.has) { const Link& L = it->second; parts.push_back({L.mass, add(p, Rot * L.com), Rot * L.Rl * L.I * L.Rl.T() * Rot.T()}); }
+        const auto ch = R.children.find(link);
+        if (ch == R.children.end()) return;
+        for (const Joint* j : ch->second) if (j->type == "fixed") go(R, j->child, add(p, Rot * j->xyz), Rot * j->R, parts);
+    } };
+    auto lump = [&](const std::string& link, int b) {
+        std::vector<Part> parts;
+        Merge::go(robot, link, V3{0, 0, 0}, M3::I(), parts);
+        if (parts.empty()) throw std::runtime_error("Link without inertial data: " + link);
+        double m = 0; V3 c{0, 0, 0};
+        for (const Part& q : parts) { m += q.m; for (int i = 0; i < 3; i++) c[i] += q.m * q.c[i]; }
+        for (double& x : c) x /= m;
+        M3 I{};
+        for (const Part& q : parts) {
+            const V3 d = sub(q.c, c);
+            const double dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) I.m[i][j] += q.I.m[i][j] + q.m * ((i == j ? dd : 0.0) - d[i] * d[j]);
+        }
+        out->body_mass[b] = m;
+        for (int i = 0; i < 3; i++) out->body_com[b][i] = c[i];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) out->body_inertia[b][3 * i + j] = I.m[i][j];
+    };
+    const Joint* fl = robot.joint("FL_hip_joint");
+    if (!fl) throw std::runtime_error("No FL_hip_joint in the URDF.");
+    lump(fl->parent, 0);                                         // the trunk: the link the hips hang on
+    const char* legs[4] = {"FL", "FR", "RL", "RR"};
+    const char* part[3] = {"_hip_joint", "_thigh_joint", "_calf_joint"};
+    for (int e = 0; e < 4; e++)
+        for (int k = 0; k < 3; k++) {
+            const Joint* j = robot.joint(std::string(legs[e]) + part[k]);
+            if (!j) throw std::runtime_error(std::string("No ") + legs[e] + part[k] + " in the URDF.");
+            lump(j->child, 1 + 3 * e + k);
+        }
 }
 
 }  // namespace mpc

@@ -28,6 +28,12 @@ def write_cfg_inc(cfg, path):
         f.write(arr('kInit', cfg['srb_init'])); f.write(arr('kTarget13', tgt)); f.write(arr('kTargetTangent', tt))
         gold = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'a1_constants_a1_configuration.json')))
         f.write(arr('kInitConfig', gold['source']['init_config']))
+        # whole-body controller gains (row f3; tests/cpp/wbc_callsites.cpp)
+        for name, key in [('kTorqueBounds', 'torque_bounds'), ('kKpJoint', 'kp_joint_gains'), ('kKdJoint', 'kd_joint_gains'), ('kBasePosGains', 'base_pos_gains'),
+                          ('kBaseAngGains', 'base_ang_gains')]:
+            f.write(arr(name, cfg[key]))
+        for name, key in [('kLegWeight', 'leg_tracking_weight'), ('kTorsoWeight', 'torso_tracking_weight'), ('kForceWeight', 'force_tracking_weight')]:
+            f.write('static const double %s = %r;\n' % (name, float(cfg[key])))
 
 
 def build_program(tmpdir):
@@ -91,6 +97,45 @@ def build_callsites(tmpdir):
     libdir = os.path.dirname(host.LIB_PATH)
     subprocess.check_call(['g++', '-std=c++17', '-O1', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), '-I', tmpdir,
                            os.path.join(CPP, 'controller_callsites.cpp'), '-o', exe, '-L', libdir, '-lsrbm_rti', '-Wl,-rpath,' + libdir])
+    return cfg, exe
+
+
+def write_urdf_from_golden(path):
+    """A URDF with the structure the library is built for -- floating base, trunk, four legs of (hip x, thigh y, calf y) revolute joints and a
+    fixed foot frame -- written from the committed constants tests/golden/a1_constants_a1_configuration.json (leg joint origins, the thirteen
+    bodies with fixed links already merged).  It is DATA for the facade's URDF reader: reading it back must reproduce those constants."""
+    gold = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'a1_constants_a1_configuration.json')))
+    v3 = lambda v: ' '.join(repr(float(x)) for x in v)
+    def link(name, body):
+        if body is None:
+            return '  <link name="%s"/>\n' % name
+        I = np.array(body['inertia'])
+        return ('  <link name="%s">\n    <inertial>\n      <origin rpy="0 0 0" xyz="%s"/>\n      <mass value="%r"/>\n'
+                '      <inertia ixx="%r" ixy="%r" ixz="%r" iyy="%r" iyz="%r" izz="%r"/>\n    </inertial>\n  </link>\n' %
+                (name, v3(body['com']), float(body['mass']), float(I[0, 0]), float(I[0, 1]), float(I[0, 2]), float(I[1, 1]), float(I[1, 2]), float(I[2, 2])))
+    def joint(name, typ, parent, child, xyz, axis=None):
+        ax = '    <axis xyz="%s"/>\n' % v3(axis) if axis is not None else ''
+        return '  <joint name="%s" type="%s">\n    <origin rpy="0 0 0" xyz="%s"/>\n    <parent link="%s"/>\n    <child link="%s"/>\n%s  </joint>\n' % (name, typ, v3(xyz), parent, child, ax)
+    out = '<?xml version="1.0"?>\n<robot name="quadruped_from_constants">\n' + link('base', None) + joint('floating_base', 'fixed', 'base', 'trunk', [0, 0, 0]) + link('trunk', gold['body_model'][0])
+    for e, leg in enumerate(('FL', 'FR', 'RL', 'RR')):
+        o = gold['leg_origins'][leg]
+        out += joint(leg + '_hip_joint', 'revolute', 'trunk', leg + '_hip', o[0], [1, 0, 0]) + link(leg + '_hip', gold['body_model'][1 + 3 * e])
+        out += joint(leg + '_thigh_joint', 'revolute', leg + '_hip', leg + '_thigh', o[1], [0, 1, 0]) + link(leg + '_thigh', gold['body_model'][2 + 3 * e])
+        out += joint(leg + '_calf_joint', 'revolute', leg + '_thigh', leg + '_calf', o[2], [0, 1, 0]) + link(leg + '_calf', gold['body_model'][3 + 3 * e])
+        out += joint(leg + '_foot_fixed', 'fixed', leg + '_calf', leg + '_foot', o[3]) + link(leg + '_foot', None)
+    out += '</robot>\n'
+    open(path, 'w').write(out)
+    return gold
+
+
+def build_wbc_callsites(tmpdir):
+    cfg = host.load_config('a1_configuration')
+    host.build()
+    write_cfg_inc(cfg, os.path.join(tmpdir, 'cfg.inc'))
+    exe = os.path.join(tmpdir, 'wbc_callsites')
+    libdir = os.path.dirname(host.LIB_PATH)
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), '-I', tmpdir,
+                           os.path.join(CPP, 'wbc_callsites.cpp'), '-o', exe, '-L', libdir, '-lsrbm_rti', '-Wl,-rpath,' + libdir])
     return cfg, exe
 
 
@@ -189,3 +234,75 @@ def test_mpc_facade_runs_the_controller_protocol_like_the_ctypes_path(tmp_path):
     assert np.array_equal(np.array(vals['contact_time']), np.concatenate(t2.get_contact_times()))
     assert np.array_equal(np.array(vals['box_center']), g.ee_box_center().reshape(-1))
     assert vals['viz'] == [5.0, 21.0]
+
+
+def check_urdf_constants(vals, gold):
+    assert abs(vals['urdf_mass'][0] - gold['mass']) < 1e-12
+    assert np.abs(np.array(vals['urdf_Ir']) - np.array(gold['Ir']).reshape(-1)).max() < 1e-11
+    hips = np.array([gold['hip_xy'][k] for k in ('FL', 'FR', 'RL', 'RR')]).reshape(-1)
+    assert np.abs(np.array(vals['urdf_hip']) - hips).max() < 1e-12
+    legs = np.array([gold['leg_origins'][k] for k in ('FL', 'FR', 'RL', 'RR')]).reshape(-1)
+    assert np.array_equal(np.array(vals['urdf_leg']), legs)
+    assert np.abs(np.array(vals['urdf_body_mass']) - np.array([b['mass'] for b in gold['body_model']])).max() < 1e-12
+    assert np.abs(np.array(vals['urdf_body_com']) - np.array([b['com'] for b in gold['body_model']]).reshape(-1)).max() < 1e-12
+    assert np.abs(np.array(vals['urdf_body_inertia']) - np.array([b['inertia'] for b in gold['body_model']]).reshape(-1)).max() < 1e-12
+
+
+def test_row_f3_call_sites_compile_and_the_urdf_reader_gives_the_kinematics_and_body_constants(tmp_path):
+    """controllers/mpc_controller.cpp:160-226 and :414-511 (targets from the trajectory, the whole-body QP) transcribed in
+    tests/cpp/wbc_callsites.cpp compile warning-free against include/mpc_facade/controllers.h (controller::QPControl,
+    mpc::SingleRigidBodyModel with the reference's signatures); the facade's URDF reader gives the leg geometry and the thirteen merged bodies
+    the library needs -- from a URDF written out of the committed constants and, where the reference's asset is present (this container, not
+    the GPU box), from models/a1_description/urdf/a1.urdf, whose fixed links (imu, rotors ... feet) it has to merge itself."""
+    cfg, exe = build_wbc_callsites(str(tmp_path))
+    urdf = os.path.join(str(tmp_path), 'from_constants.urdf')
+    gold = write_urdf_from_golden(urdf)
+    check_urdf_constants(parse_dump(subprocess.check_output([exe, urdf, '0'], text=True)), gold)
+    ref = '/root/reference/models/a1_description/urdf/a1.urdf'
+    if os.path.exists(ref):
+        check_urdf_constants(parse_dump(subprocess.check_output([exe, ref, '0'], text=True)), gold)
+
+
+@pytest.mark.gpu
+def test_row_f3_facade_runs_the_control_tick_like_the_ctypes_path(tmp_path):
+    """MPCController::ComputeControlAction through controller::QPControl / mpc::SingleRigidBodyModel / mpc::MPCSingleRigidBody (two single
+    IK calls and the host-side interpolation of the reference's text) against the fused batch entries of the Python binding
+    (srbm_get_targets_from_traj, srbm_qp_control) on the same protocol: targets <= 1e-9, control action <= 1e-6 relative."""
+    cfg, exe = build_wbc_callsites(str(tmp_path))
+    urdf = os.path.join(str(tmp_path), 'from_constants.urdf')
+    gold = write_urdf_from_golden(urdf)
+    TICKS = 5
+    vals = parse_dump(subprocess.check_output([exe, urdf, str(TICKS)], text=True))
+    assert vals['tick_status'] == [0.0] * TICKS and vals['run_num'] == [float(TICKS)]
+    s0 = np.array(cfg['srb_init'], float)
+    q0 = np.array(gold['source']['init_config'], float)
+    g = host.BatchMPC(cfg, 1)
+    g.set_state_trajectory_warm_start(s0)
+    g.add_force_cost(cfg['force_cost'])
+    ee0 = g.forward_kinematics(q0)[0]
+    ee0[:, 2] = 0
+    g.create_initial_run(s0, ee0.reshape(1, 12))
+    traj = g.get_trajectory()[0]
+    for i in range(3):
+        t = i * cfg['integrator_dt']
+        state = traj.get_states()[1]
+        ee = np.array([traj.get_end_effector_location(e, t) for e in range(4)]).reshape(1, 12)
+        g.get_real_time_update(state, t, ee)
+        traj = g.get_trajectory()[0]
+    t0 = traj.init_time
+    assert vals['t0'][0] == t0
+    q_des = q0.reshape(1, 19).copy(); v_des = np.zeros((1, 18))
+    for k in range(TICKS):
+        time = t0 + 1e-3 * (k + 1)
+        q_meas = q_des.copy(); q_meas[0, 7:] += 0.01 * ((np.arange(12) % 3) - 1)
+        v_meas = 0.9 * v_des
+        q_des, v_des, f_des, st = g.get_targets_from_traj(time, q_des)
+        assert st[0] == 0
+        _, _, con = g.eval_trajectory(time)
+        fd = np.zeros((1, 12)); sel = f_des[0][con[0] > 0].reshape(-1); fd[0, :sel.size] = sel
+        ctl, sol, stq, itq = g.qp_control(q_meas, v_meas, con, q_des, v_des, fd)
+        assert stq[0] <= 1
+    assert np.array_equal(np.array(vals['contact']), con[0].astype(float))
+    assert np.abs(np.array(vals['q_des']) - q_des[0]).max() < 1e-9, np.abs(np.array(vals['q_des']) - q_des[0]).max()
+    assert np.abs(np.array(vals['v_des']) - v_des[0]).max() < 1e-6 * max(1.0, np.abs(v_des).max())
+    assert np.abs(np.array(vals['control']) - ctl[0]).max() < 1e-6 * max(1.0, np.abs(ctl).max()), np.abs(np.array(vals['control']) - ctl[0]).max()
