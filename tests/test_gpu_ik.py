@@ -104,3 +104,28 @@ def test_full_batch_targets_properties():
     ff, _, _ = g.eval_trajectory(t)
     assert np.array_equal(f, ff)
     assert np.abs(v[:, 6:]).max() < 100                 # the reference warns above 100 rad/s
+
+
+def test_target_failures_agree_with_the_oracle():
+    """After 7 RTI steps of the perturbed Config-B batch a fifth of the target solves cannot reach the planned foot positions (the reference
+    throws "IK did not converge."): the device reports exactly the instances the numpy restatement fails on, and equal targets on the others"""
+    B = 256
+    cfg, legs, q0, g = setup(B)
+    states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees).reshape(B, 12)
+    g.set_state_trajectory_warm_start(states)
+    g.create_initial_run(states, ees)
+    g.rti_advance(0, 7); g.synchronize()
+    trajs = g.get_trajectory()
+    Ir_inv = np.linalg.inv(np.array(cfg['Ir']))
+    t = trajs[0].init_time + 1e-3
+    q, v, f, st = g.get_targets_from_traj(t, np.tile(q0, (B, 1)))
+    bad, good = np.where(st == 1)[0], np.where(st == 0)[0]
+    assert len(bad) > 10 and len(good) > 100 and len(bad) + len(good) == B
+    for b in list(bad[:5]) + list(good[:5]):
+        tr = trajs[b]
+        qo, vo, fo, ok = ik.targets_from_traj(legs, tr.get_states(), tr.init_time, tr.node_dt, cfg['mass'], Ir_inv,
+                                              lambda e, tt: tr.get_end_effector_location(e, tt), lambda e, tt: tr.get_force(e, tt), t, q0)
+        assert ok == (st[b] == 0), (b, st[b], ok)
+        if ok:
+            assert np.abs(q[b] - qo).max() < 1e-8 and np.abs(v[b] - vo).max() < 1e-6, b
