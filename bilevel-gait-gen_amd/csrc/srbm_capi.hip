@@ -159,7 +159,6 @@ __global__ void srbm_k_init(const SrbmParams* __restrict__ Pp, SrbmInst* __restr
     I.status = SRBM_UNSOLVED; I.qp_iters = 0; I.n = 0; I.m = 0; I.n_eq = 0; I.n_ineq = 0; I.nfv = 0; I.npv = 0; I.n_td = 0; I.n_samples = 0;
     I.err = 0; I.run_num = 0; I.acc_iters = 0; I.acc_flops = 0;
     I.cost_sum = 0; I.merit_dd = 0; I.acc_mfma = 0; I.err_acc = 0; I.n_solves = 0; I.n_not_solved = 0; I.n_maxiter = 0;
-    I.low_skip = 0; I.n_low_tried = 0; I.n_low_failed = 0; I.pad_low = 0;
 }
 
 __global__ void srbm_k_warm_start(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, const double* __restrict__ states) {
@@ -1507,15 +1506,6 @@ int srbm_get_executed_mfma(srbm_batch* h, double* total) {
     double t = 0;
     for (auto& I : v) t += I.acc_mfma;
     *total = t;
-    return 0;
-}
-int srbm_get_start_counters(srbm_batch* h, double* tried, double* failed) {
-    if (!h || !tried || !failed) return fail("bad arguments");
-    std::vector<SrbmInst> v;
-    if (fetch_insts(h, v)) return -1;
-    double t = 0, f = 0;
-    for (auto& I : v) { t += I.n_low_tried; f += I.n_low_failed; }
-    *tried = t; *failed = f;
     return 0;
 }
 

@@ -77,7 +77,6 @@ typedef struct SrbmInst {
     double merit_dd;                              /* directional derivative of the L1 merit along the step of the last solve (mpc.cpp:783-788; the 'Merit dd' column of the statistics log) */
     double acc_mfma;                              /* v_mfma_f64_16x16x4_f64 instructions EXECUTED (per wave) by the condensing and IPM phases: the executed-flop side of the roofline */
     int err_acc, n_solves, n_not_solved, n_maxiter;       /* n_not_solved: status not in {Solved, SolvedInacc}; n_maxiter: of those, MaxIter */
-    int low_skip, n_low_tried, n_low_failed, pad_low;     /* lower start of the IPM (srbm_k3_ipm.hiph): solves to skip it after a failure; attempts / failures so far */
 } SrbmInst;
 
 /* per (node, foot) linearisation record */

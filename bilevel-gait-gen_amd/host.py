@@ -292,12 +292,6 @@ class BatchMPC:
     def clear_status_accumulators(self):
         self._chk(self.L.srbm_clear_status_accumulators(self.h))
 
-    def start_counters(self):
-        """(solves first tried from the lower starting point, of those repeated from the standard one)"""
-        t = C.c_double(0); f = C.c_double(0)
-        self._chk(self.L.srbm_get_start_counters(self.h, C.byref(t), C.byref(f)))
-        return t.value, f.value
-
     def executed_mfma(self):
         v = C.c_double(0)
         self._chk(self.L.srbm_get_executed_mfma(self.h, C.byref(v)))

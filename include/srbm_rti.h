@@ -277,9 +277,6 @@ int srbm_get_work_counters(srbm_batch* h, double* total_ipm_iterations, double* 
  * phases, summed over the batch: the executed-flop side of the roofline (the algorithmic figure counts a dense SYRK that the
  * structured assembly never performs) */
 int srbm_get_executed_mfma(srbm_batch* h, double* total_mfma_instructions);
-/* solves of the batch so far that were first tried from the lower starting point of the interior-point method (srbm_k3_ipm.hiph) and, of those, the
- * ones repeated from the standard starting point because the attempt did not end Solved (both 0 in a build without the attempt) */
-int srbm_get_start_counters(srbm_batch* h, double* tried, double* failed);
 /* bytes of HBM held per instance (persistent record + per-solve workspace) */
 long srbm_bytes_per_instance(void);
 
