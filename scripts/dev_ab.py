@@ -20,6 +20,13 @@ if len(sys.argv) > 1 and sys.argv[1] == '--child':
     if 'AB_TOL' in os.environ: g.set_solver_tolerances(float(os.environ['AB_TOL']), float(os.environ['AB_TOL']), 1e-10, 200)
     for _ in range(10): g.create_initial_run(states, ees)
     g.rti_advance(0, 5); g.synchronize()
+    if os.environ.get('AB_WINDOWS'):      # five 20-step launches timed one by one (the bench's timed regions)
+        w = []
+        for k in range(5):
+            ta = time.perf_counter(); g.rti_advance(5 + 20 * k, 20); g.synchronize(); w.append((time.perf_counter() - ta) / 20 * 1e3)
+        acc = g.status_accumulated()
+        print('%-20s windows ms/step %s  median %.3f  not solved %d  err bits %d' % (os.path.basename(os.environ['SRBM_RTI_LIB']), ' '.join('%.3f' % v for v in w), sorted(w)[2],
+              int(acc[:, 2].sum()), int(np.bitwise_or.reduce(acc[:, 0]))))
     t0 = time.perf_counter(); g.rti_advance(5, 40); g.synchronize(); t1 = time.perf_counter()
     st = g.status()[0]; x = g.qp_solution()
     print('%-40s tol %s  %.3f ms/step  iters %.2f  statuses %s  checksum %.17g' % (os.path.basename(os.environ['SRBM_RTI_LIB']), os.environ.get('AB_TOL', 'default'), (t1 - t0) / 40 * 1e3,
