@@ -474,3 +474,33 @@ def test_capacity_overflow_fails_loudly():
     g.get_real_time_update(s0, 0.0, EE0)
     st, err = g.status()
     assert (err[0] & 16) != 0 and st[0] == 8
+
+
+def test_infeasible_qps_of_the_pushed_configuration_are_infeasible_for_the_oracle_too():
+    """Config D (N = 50, pushes on the initial momentum): instances 150 and 441 of its seeded batch are the ones whose QPs the device reports
+    PrimalInfeasible in the bench's timed region (`all_solved: false` there).  On the SAME exported QPs the oracle's solver gives the same
+    status -- they are properties of the pushed workload, not failures of the device solver."""
+    from oracle_py import qp_solve
+    from bench import config_d_instance
+    cfg = load_config('a1_config_distr_rejection')
+    N = cfg['num_nodes']; nx = 12 * (N + 1)
+    ids = [150, 441, 3]
+    states, ees = zip(*[config_d_instance(cfg, b) for b in ids])
+    states, ees = np.array(states), np.array(ees).reshape(len(ids), 12)
+    g = host.BatchMPC(cfg, len(ids)); g.set_state_trajectory_warm_start(states)
+    g.create_initial_run(states, ees)
+    seen = {0: 0, 3: 0}
+    for i in range(15):
+        g.rti_advance(i, 1); g.synchronize()
+        st, err = g.status()
+        assert np.all(err == 0)
+        if i < 5 or i % 2:
+            continue
+        for b in range(len(ids)):
+            sz = g.sizes()[b]
+            A, bb, P, q = g.export_qp(b)
+            cones = [c for c in [(0, nx), (1, 2 * int(sz[7])), (1, 4 * int(sz[7])), (1, 2 * (N - 3) * 8), (0, int(sz[6])), (0, 8)] if c[1] > 0]
+            r = qp_solve(P, q, A, bb, cones, tol_gap=1e-15, tol_feas=1e-10)
+            assert (int(st[b]) == 3) == (r['status'] == 3), (i, ids[b], st[b], r['status'])
+            seen[3 if int(st[b]) == 3 else 0] += 1
+    assert seen[3] >= 6 and seen[0] >= 5, seen          # both kinds were compared
