@@ -1057,6 +1057,9 @@ int srbm_gait_rti_advance(srbm_gait* g, int first_run_num, int steps, int gait_o
     return 0;
 }
 /* status / stats of the candidates of the last line search: status[batch][10], iters[batch][10] (diagnostic) */
+// diagnostic / test hook: the batch of line-search candidates (LS_SIZE per instance, candidate c of instance b at index b * LS_SIZE + c), owned by
+// the gait handle -- for the read-back entries (status, sizes, srbm_export_qp) only
+srbm_batch* srbm_gait_debug_candidates(srbm_gait* g) { return g ? g->ls : nullptr; }
 int srbm_gait_get_candidate_status(srbm_gait* g, int* status, int* err) {
     if (!g || !status || !err) return fail("bad arguments");
     std::vector<SrbmInst> v;

@@ -602,6 +602,17 @@ class BatchGaitOptimizer:
         m._chk(self.L.srbm_gait_line_search(self.g, _d(s), _d(t), _d(e), _i(imin), _d(costs)))
         return imin, costs
 
+    def candidates(self):
+        """the candidate batch of the last line search as a BORROWED BatchMPC view (read-back entries only): candidate c of instance b at b * 10 + c"""
+        self.L.srbm_gait_debug_candidates.restype = C.c_void_p
+        v = object.__new__(BatchMPC)
+        m = self.mpc
+        v.N, v.large, v.L, v.NUMAX, v.NSMAX, v.cfg = m.N, m.large, m.L, m.NUMAX, m.NSMAX, m.cfg
+        v.batch = m.batch * self.LS_SIZE
+        v.h = C.c_void_p(self.L.srbm_gait_debug_candidates(self.g))
+        v.close = lambda: None                      # not ours to destroy
+        return v
+
     def candidate_status(self):
         n = self.mpc.batch * self.LS_SIZE
         st = np.zeros(n, np.int32); err = np.zeros(n, np.int32)

@@ -188,6 +188,9 @@ int srbm_gait_line_search(srbm_gait* g, const double* state, const double* init_
 int srbm_gait_rti_advance(srbm_gait* g, int first_run_num, int steps, int gait_opt_freq);
 /* solver status / error bits of the candidates of the last line search: status[batch*10], err[batch*10] */
 int srbm_gait_get_candidate_status(srbm_gait* g, int* status, int* err);
+/* test hook: the candidate batch of the last line search (borrowed: never destroy it), candidate c of instance b at b * 10 + c; for the
+ * read-back entries (srbm_get_status, srbm_get_sizes, srbm_export_qp) */
+srbm_batch* srbm_gait_debug_candidates(srbm_gait* g);
 
 /* ---- trajectory -> whole-body targets: the step right downstream of the MPC in the reference's
  * controller.  q = [base position (3), base quaternion xyzw (4), 12 joint angles in pinocchio's model order FL FR RL RR x

@@ -261,6 +261,12 @@ int orc_gait_line_search(void* p, const double* state13, double t, const double*
     try { return h->gait->LineSearch(*h->mpc, t, ee_from(ee12), st_from(state13), costs10); }
     catch (const std::exception& e) { h->err = e.what(); return -1; }
 }
+// the same with the solve quality of every candidate (mpc::SolveQuality values)
+int orc_gait_line_search_q(void* p, const double* state13, double t, const double* ee12, double* costs10, int* quality10) {
+    auto* h = static_cast<OrcMPC*>(p);
+    try { return h->gait->LineSearch(*h->mpc, t, ee_from(ee12), st_from(state13), costs10, quality10); }
+    catch (const std::exception& e) { h->err = e.what(); return -1; }
+}
 
 // ---- generic QP entry (used to pin the solver restatement on the reference's 3-variable fixture) ----
 int orc_qp_solve(int n, int m, int nnzP, const int* Pr, const int* Pc, const double* Pv, const double* q, int nnzA,

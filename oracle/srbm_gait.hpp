@@ -324,7 +324,8 @@ public:
     }
 
     // gait_optimizer.cpp:671-753.  Returns argmin index (0 if every candidate was primal infeasible).
-    int LineSearch(MPCSingleRigidBody& mpc, double time, const std::vector<Vec3>& ee, const Vec13& state, double* costs_out) {
+    // (quality_out: the solve quality of every candidate, for the tests; may be nullptr)
+    int LineSearch(MPCSingleRigidBody& mpc, double time, const std::vector<Vec3>& ee, const Vec13& state, double* costs_out, int* quality_out = nullptr) {
         double costs[LS_SIZE];
         SolveQuality quality[LS_SIZE];
         std::vector<Trajectory> trajs(LS_SIZE, mpc.GetTrajectory());
@@ -337,6 +338,7 @@ public:
             trajs[i] = mpc_ls.GetTrajectory();
             quality[i] = mpc_ls.GetSolveQuality();
             if (costs_out) costs_out[i] = costs[i];
+            if (quality_out) quality_out[i] = (int)quality[i];
         }
         int imin = -1;
         double cmin = 1e10;

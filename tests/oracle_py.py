@@ -267,6 +267,14 @@ class OracleMPC:
         k = self._chk(self.L.orc_gait_line_search(self.h, _d(s), C.c_double(t), _d(e), _d(costs)))
         return k, costs
 
+    def gait_line_search_with_quality(self, state13, t, ee):
+        """-> (argmin, costs[10], mpc::SolveQuality of every candidate's solve)"""
+        s = np.ascontiguousarray(state13, dtype=np.float64)
+        e = np.ascontiguousarray(ee, dtype=np.float64).reshape(-1)
+        costs = np.zeros(10); q = np.zeros(10, np.int32)
+        k = self._chk(self.L.orc_gait_line_search_q(self.h, _d(s), C.c_double(t), _d(e), _d(costs), _i(q)))
+        return k, costs, q
+
 
 def qp_solve(P, q, A, b, cones, tol_gap=1e-8, tol_feas=1e-8):
     """cones: list of (is_nonneg, dim).  P dense symmetric, A dense."""
