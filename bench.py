@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (public spec; the CDNA guide lists no fp64 row)
 MFMA_FLOP = 2048.0           # one v_mfma_f64_16x16x4_f64: 16 x 16 x 4 multiply-adds
 BATCH_PER_GPU = 256
-PROFILE_ROUND = 'r02'
+PROFILE_ROUND = 'r03'
 
 
 # ---------- helpers shared with the CPU (gloo) tests of the sharding logic ----------
@@ -213,11 +213,30 @@ def spawn_ranks(args):
     port = free_port()
     procs = []
     for r in range(args.gpus):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: the hosts of this pool only support dmabuf IPC -- without it RCCL's cross-process buffer exchange fails
+        # with `hipIpcGetMemHandle: invalid argument`; kept if the caller already exports it, set otherwise
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rcs = [p.wait() for p in procs]
-    return max(abs(rc) for rc in rcs)
+    # poll: the first rank that fails ends the run (its peers would otherwise sit in the rendezvous / a barrier until the RCCL timeout)
+    rc = 0
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.2)
+        for p in list(live):
+            r = p.poll()
+            if r is not None:
+                live.remove(p)
+                if r != 0:
+                    rc = abs(r)
+    for p in live:
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc
 
 
 def main():
@@ -293,7 +312,9 @@ def main():
     # (rehearsal of that path on a one-GPU box)
     DIST = world > 1 or os.environ.get('SRBM_BENCH_FORCE_DIST') == '1'
     if DIST:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if 'MASTER_PORT' not in os.environ:
+            os.environ['MASTER_PORT'] = str(free_port())      # (one-rank rehearsal: no peer needs to know it)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     states, ees = zip(*[make_instance(cfg, b) for b in range(lo, hi)])
@@ -316,8 +337,10 @@ def main():
     mf0 = mpc.executed_mfma()
     mpc.enable_kernel_timing(args.repeats + 2)     # every timed region is ONE launch of the fused RTI kernel
     region_s = []
+    region_work = []                          # (IPM iterations, algorithmic flops, executed MFMA) of each region's launch
     first = args.warmup
     allrec = None
+    prev_ctr = (it0, fl0, mf0)
     for rep in range(args.repeats):
         if DIST:
             dist.barrier()
@@ -331,13 +354,19 @@ def main():
         if DIST:
             dist.barrier()
         region_s.append(max_over_ranks(time.perf_counter() - t0))
+        ctr = mpc.work_counters() + (mpc.executed_mfma(),)          # (outside the timed region)
+        region_work.append(tuple(a - b for a, b in zip(ctr, prev_ctr)))
+        prev_ctr = ctr
         first += args.steps
     elapsed = float(np.median(region_s))
+    med = int(np.argsort(region_s)[len(region_s) // 2])            # the region `value` is computed from
 
-    k3_ms, k3_launches = mpc.kernel_timing()
+    k3_each = mpc.kernel_timings(args.repeats + 2)
+    k3_launches = len(k3_each)
     it1, fl1 = mpc.work_counters()
     mf1 = mpc.executed_mfma()
     acc_main = mpc.status_accumulated()
+    ctrs = mpc.solver_counters()
 
     # ---- second segment (Config C): N=20 / dt=0.05 with the values of apps/a1_gait_opt_config.yaml, gait step every 5th iteration ----
     gait_stats = None
@@ -466,17 +495,25 @@ def main():
         err_all = allrec[:, 5].cpu().numpy().astype(np.int64)
         if allrec.shape[0] != n_inst:
             raise SystemExit('gathered %d records for %d instances' % (allrec.shape[0], n_inst))
-        k3_avg_s = (k3_ms / max(1, k3_launches)) * 1e-3
-        flops_per_launch = (fl1 - fl0) / max(1, k3_launches)
-        mfma_per_launch = (mf1 - mf0) / max(1, k3_launches)
+        # the roofline object describes the SAME region `value` does: the median one -- its own launch duration (HIP events on the launch
+        # stream), its own flop and MFMA counts
+        k3_avg_s = float(k3_each[med]) * 1e-3 if med < k3_launches else 0.0
+        flops_per_launch = region_work[med][1]
+        mfma_per_launch = region_work[med][2]
         achieved = flops_per_launch / k3_avg_s / 1e12 if k3_avg_s > 0 else 0.0
         exec_tflops = mfma_per_launch * MFMA_FLOP / k3_avg_s / 1e12 if k3_avg_s > 0 else 0.0
         traffic, pmc = pmc_traffic(args.steps) if args.workload == 'B' else (None, None)
-        roof = {'bound': 'mfma', 'limiter': 'latency of dependent chains (1 workgroup of 8 waves per CU, no HBM or matrix-pipe saturation)',
+        # `bound` keeps to the schema of the measurement contract (hbm | mfma): it names the roof `frac` is priced against.  What limits the
+        # kernel in practice is neither -- `limiter` says so in one word, `limiter_detail` in a sentence
+        roof = {'bound': 'mfma', 'limiter': 'latency',
+                'limiter_detail': 'latency of dependent chains (1 workgroup of 8 waves per CU, no HBM or matrix-pipe saturation); frac is measured against '
+                                  'the fp64 matrix roof, the nearest one',
+                'statistic': 'median region (index %d of %d): the launch `value` is computed from' % (med, len(region_s)),
+                'launch_ms_all': [float(v) for v in k3_each],
                 'kernel': ('srbm_rti_fused' if cfg['num_nodes'] <= 22 else 'srbm_rti_fused_long') + (' (LARGE build)' if mpc.large else ''),
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_PEAK_TFLOPS,
                 'achieved_is': 'ALGORITHMIC flops (SURVEY.md 8d formula at the sizes and IPM iteration counts executed) / measured launch time',
-                'traffic': traffic, 'avg_launch_ms': k3_avg_s * 1e3, 'launches_timed': k3_launches,
+                'traffic': traffic, 'avg_launch_ms': k3_avg_s * 1e3, 'launches_timed': k3_launches, 'ipm_iterations_per_solve_in_this_launch': region_work[med][0] / max(1, (hi - lo) * args.steps),
                 'algorithmic_flops_per_launch': flops_per_launch,
                 'executed_mfma_tflops': exec_tflops, 'executed_mfma_frac_of_peak': exec_tflops / FP64_PEAK_TFLOPS,
                 'executed_mfma_instructions_per_launch': mfma_per_launch}
@@ -501,7 +538,11 @@ def main():
                        'all_solved': bool(q[2] == 0 and q[0] == 0), 'statuses_last_step': {int(k): int(v) for k, v in zip(*np.unique(status_all, return_counts=True))},
                        'timed_solves': int(q[1]), 'not_solved_in_timed_solves': int(q[2]), 'max_iter_in_timed_solves': int(q[3]),
                        'err_bits_all_timed_steps': int(q[0]) | int(np.bitwise_or.reduce(err_all)),
-                       'mean_ipm_iterations': (it1 - it0) / max(1, (hi - lo) * args.steps * args.repeats)},
+                       'mean_ipm_iterations': (it1 - it0) / max(1, (hi - lo) * args.steps * args.repeats),
+                       'solver': {'tol_gap': 1e-15, 'tol_feas': 1e-10, 'tol_step': mpc.solver_step_rule()[0], 'start_mu': mpc.solver_step_rule()[1],
+                                  'solves_ended_by_step_rule': ctrs['step_rule'], 'lower_start_attempts': ctrs['low_tried'],
+                                  'attempts_repeated_from_standard_start': ctrs['low_failed'], 'solves_counted': ctrs['solves'],
+                                  'note': 'rank 0, all solves since the accumulators were cleared (timed regions; include/srbm_rti.h srbm_set_solver_step_rule)'}},
             'roofline': roof,
         }
         if gait_stats is not None:

@@ -10,9 +10,13 @@
 #include "srbm_k4_update.hiph"
 #include "srbm_gait.hiph"
 #include "srbm_plant.hiph"
+#include "srbm_fused.hiph"
 #include "srbm_ik.hiph"
 #include "srbm_wbc.hiph"
 #include "../../include/srbm_rti.h"
+#ifndef SRBM_LARGE
+#include "srbm_co.h"           // the co-resident kernel set (two instances per CU) for batches beyond the CU count
+#endif
 
 #ifdef SRBM_LARGE
 #define SRBM_DYN_LDS(T) sizeof(T)        /* LARGE build: the working sets of kernels 1, 2, 4 exceed 64 KB of static LDS */
@@ -35,6 +39,12 @@ struct srbm_batch {
     hipStream_t stream = nullptr;
     bool owns_stream = true;
     size_t k3_lds = 0;
+    // kernel set: 0 = standard (512 threads, normal matrix in LDS, one instance per CU), 1 = co-resident (srbm_co.h).  Chosen by the batch size
+    // at creation (more instances than CUs -> co-resident), srbm_set_kernel_set overrides.  dp_co: the parameters with the co-resident LDS size
+    int kernel_set = 0;
+    bool co_available = false;
+    SrbmParams* dp_co = nullptr;
+    size_t k3_lds_co = 0;
     bool params_dirty = true;
     // optional HIP-event timing of the dominant kernel (srbm_k3_ipm) on the launch stream
     bool timing = false;
@@ -159,96 +169,12 @@ __global__ void srbm_k_init(const SrbmParams* __restrict__ Pp, SrbmInst* __restr
     I.status = SRBM_UNSOLVED; I.qp_iters = 0; I.n = 0; I.m = 0; I.n_eq = 0; I.n_ineq = 0; I.nfv = 0; I.npv = 0; I.n_td = 0; I.n_samples = 0;
     I.err = 0; I.run_num = 0; I.acc_iters = 0; I.acc_flops = 0;
     I.cost_sum = 0; I.merit_dd = 0; I.acc_mfma = 0; I.err_acc = 0; I.n_solves = 0; I.n_not_solved = 0; I.n_maxiter = 0;
+    I.low_streak = 0; I.last_rule = 0; I.low_skip = 0; I.n_low_tried = 0; I.n_low_failed = 0; I.n_step_rule = 0;
 }
 
 __global__ void srbm_k_warm_start(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, const double* __restrict__ states) {
     const int b = blockIdx.x, tid = threadIdx.x;
     for (int i = tid; i < (Pp->N + 1) * 13; i += blockDim.x) insts[b].states[i] = states[(size_t)b * 13 + (i % 13)];
-}
-
-// inputs of the next open-loop iteration (test/gait_opt_playground.cpp:113-126)
-__device__ __forceinline__ void srbm_next_inputs_body(const SrbmParams* __restrict__ Pp, const SrbmInst* __restrict__ insts, double time,
-                                                      double* __restrict__ state_out, double* __restrict__ time_out, double* __restrict__ ee_out) {
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const SrbmInst& I = insts[b];
-    if (tid < 13) state_out[(size_t)b * 13 + tid] = I.states[13 + tid];
-    if (tid == 13) time_out[b] = time;
-    if (tid >= 16 && tid < 16 + SRBM_NEE) {
-        const int ee = tid - 16;
-        FootView f{I.knot_t[ee], I.kind[ee], I.nk[ee]};
-        int err = 0;
-        double xy[2];
-        srbm_posxy_value(f, &I.pval[ee][0][0], time, xy, &err);
-        const double z = srbm_posz_value(f, time, Pp->swing_height, Pp->foot_offset, &err);
-        ee_out[(size_t)b * 12 + ee * 3] = xy[0]; ee_out[(size_t)b * 12 + ee * 3 + 1] = xy[1]; ee_out[(size_t)b * 12 + ee * 3 + 2] = z;
-    }
-}
-__global__ void srbm_k_next_inputs(const SrbmParams* __restrict__ Pp, const SrbmInst* __restrict__ insts, double time,
-                                   double* __restrict__ state_out, double* __restrict__ time_out, double* __restrict__ ee_out) {
-    srbm_next_inputs_body(Pp, insts, time, state_out, time_out, ee_out);
-}
-
-// The whole open-loop protocol of test/gait_opt_playground.cpp:113-126 in ONE launch: every workgroup walks its own
-// instance through `steps` RTI iterations (next inputs -> assemble -> condense -> IPM -> update), the phases separated by
-// workgroup barriers only.  No grid-wide synchronisation between the phases or the steps: an instance that needs 18 IPM
-// iterations in a step does not wait for the one that needs 25, the imbalance averages out over the steps.  The
-// working sets of kernels 1, 2 and 4 are windows of the IPM kernel's dynamic LDS.
-// Each phase is an out-of-line function: its registers are allocated for that phase alone (inlined into one body, values of
-// one phase were kept live -- spilled -- across the others and out of the step loop).
-// Everything between two solves is ONE out-of-line function -- update of step s (when `update`), then inputs, assembly and
-// condensing of step s+1 (when `next`): an out-of-line function saves the callee-saved registers it uses on entry (448 B
-// per lane here, it uses all of them), so fewer, larger phases mean less scratch traffic per step.
-static __device__ __noinline__ void srbm_phase_between_solves(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works,
-                                                              int update, int next, double time, double* __restrict__ d_state, double* __restrict__ d_time,
-                                                              double* __restrict__ d_ee, double* __restrict__ plant, const double* __restrict__ push_time,
-                                                              const double* __restrict__ push_impulse, int substeps, int advance_time) {
-    if (update) {
-        srbm_k4_update_body(Pp, insts, works, *reinterpret_cast<K4Shared*>(k3_smem));
-        __syncthreads();
-    }
-    if (next) {
-        if (plant) srbm_plant_inputs_body(Pp, insts, time, substeps, advance_time, plant, push_time, push_impulse, d_state, d_time, d_ee);
-        else srbm_next_inputs_body(Pp, insts, time, d_state, d_time, d_ee);
-        __syncthreads();
-        srbm_k1_assemble_body(Pp, insts, works, d_state, d_time, d_ee, *reinterpret_cast<K1Shared*>(k3_smem));
-        __syncthreads();
-        srbm_k2_condense_body(Pp, insts, works, *reinterpret_cast<K2Shared*>(k3_smem));
-    }
-}
-template <int RPT>
-static __device__ __noinline__ void srbm_phase_ipm(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works) {
-    srbm_k3_body<0, RPT>(Pp, insts, works);
-}
-// closed-loop mode of the fused kernel: plant != nullptr (srbm_plant.hiph)
-struct SrbmPlantArgs {
-    double* plant; const double* push_time; const double* push_impulse;
-    int substeps, advance_time;
-};
-template <int RPT>
-__device__ __forceinline__ void srbm_rti_fused_body(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works,
-                                                    int first_index, int steps, double* __restrict__ d_state, double* __restrict__ d_time,
-                                                    double* __restrict__ d_ee, const SrbmPlantArgs pl) {
-    static_assert(K1_THREADS == K3_THREADS && K2_THREADS == K3_THREADS && K4_THREADS == K3_THREADS, "the fused kernel runs all phases with one block size");
-    for (int s = 0; s <= steps; s++) {
-        // between-solves phase: update of step s-1, inputs / assembly / condensing of step s
-        const double time = (first_index + s) * Pp->dt;
-        srbm_phase_between_solves(Pp, insts, works, s > 0, s < steps, time, d_state, d_time, d_ee, pl.plant, pl.push_time, pl.push_impulse, pl.substeps,
-                                  pl.advance_time);
-        __syncthreads();
-        if (s == steps) break;
-        srbm_phase_ipm<RPT>(Pp, insts, works);
-        __syncthreads();
-    }
-}
-__global__ __launch_bounds__(K3_THREADS) void srbm_rti_fused(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works,
-                                                             int first_index, int steps, double* __restrict__ d_state, double* __restrict__ d_time,
-                                                             double* __restrict__ d_ee, const SrbmPlantArgs pl) {
-    srbm_rti_fused_body<K3_RPT_SHORT>(Pp, insts, works, first_index, steps, d_state, d_time, d_ee, pl);
-}
-__global__ __launch_bounds__(K3_THREADS) void srbm_rti_fused_long(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, SrbmWork* __restrict__ works,
-                                                                  int first_index, int steps, double* __restrict__ d_state, double* __restrict__ d_time,
-                                                                  double* __restrict__ d_ee, const SrbmPlantArgs pl) {
-    srbm_rti_fused_body<K3_RPT>(Pp, insts, works, first_index, steps, d_state, d_time, d_ee, pl);
 }
 
 // EndEffectorSplines::SetContactTimes (end_effector_splines.cpp:860-892) for every foot of every instance
@@ -354,6 +280,11 @@ static int upload_params(srbm_batch* h) {
     h->hp.q_diag = 1;
     for (int i = 0; i < 144; i++) if (i % 13 != 0 && (h->hp.Q[i] != 0.0 || h->hp.Phi[i] != 0.0)) h->hp.q_diag = 0;
     HIPCHK(hipMemcpyAsync(h->dp, &h->hp, sizeof(SrbmParams), hipMemcpyHostToDevice, h->stream));
+    if (h->dp_co) {
+        SrbmParams pc = h->hp;
+        pc.lds_doubles = (int)(h->k3_lds_co / sizeof(double));
+        HIPCHK(hipMemcpyAsync(h->dp_co, &pc, sizeof(SrbmParams), hipMemcpyHostToDevice, h->stream));     // (pageable source: staged before the call returns)
+    }
     h->params_dirty = false;
     return 0;
 }
@@ -364,15 +295,30 @@ static void inv3(const double* m, double* r) {
     r[3] = (f * g - d * i) / det; r[4] = (a * i - c * g) / det; r[5] = (c * d - a * f) / det;
     r[6] = (d * hh - e * g) / det; r[7] = (b * g - a * hh) / det; r[8] = (a * e - b * d) / det;
 }
-static int launch_step(srbm_batch* h) {
+// one RTI step as four launches.  exact: the solve is taken to the gap criterion whatever the batch's step rule says (the solve whose KKT
+// sensitivity the gait step differentiates)
+static int launch_step(srbm_batch* h, bool exact = false) {
     if (upload_params(h)) return -1;
+    // (start_mu only in the fused K-step launches: the lower-start attempt trades a shorter mean for a longer tail, and a one-step launch ends with
+    //  the slowest instance of the batch -- srbm_k3_ipm.hiph)
+    const double tol_step = exact ? 0.0 : h->hp.tol_step, start_mu = 0.0;
     const int B = h->batch;
+#ifndef SRBM_LARGE
+    if (h->kernel_set == 1) {
+        const bool tmc = h->timing && h->ev_used < h->ev_start.size();
+        if (srbm_co_launch_step(h->stream, h->dp_co, h->insts, h->works, h->d_state, h->d_time, h->d_ee, B, h->hp.N, h->k3_lds_co, tol_step, start_mu,
+                                tmc ? h->ev_start[h->ev_used] : nullptr, tmc ? h->ev_stop[h->ev_used] : nullptr))
+            return fail("launch of the co-resident kernel set failed");
+        if (tmc) { h->ev_steps[h->ev_used] = 1; h->ev_used++; }
+        return 0;
+    }
+#endif
     hipLaunchKernelGGL(srbm_k1_assemble, dim3(B), dim3(K1_THREADS), SRBM_DYN_LDS(K1Shared), h->stream, h->dp, h->insts, h->works, h->d_state, h->d_time, h->d_ee);
     hipLaunchKernelGGL(srbm_k2_condense, dim3(B), dim3(K2_THREADS), SRBM_DYN_LDS(K2Shared), h->stream, h->dp, h->insts, h->works);
     const bool tm = h->timing && h->ev_used < h->ev_start.size();
     if (tm) HIPCHK(hipEventRecord(h->ev_start[h->ev_used], h->stream));
-    if (h->hp.N <= K3_SHORT_N) hipLaunchKernelGGL(srbm_k3_ipm, dim3(B), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works);
-    else hipLaunchKernelGGL(srbm_k3_ipm_long, dim3(B), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works);
+    if (h->hp.N <= K3_SHORT_N) hipLaunchKernelGGL(srbm_k3_ipm, dim3(B), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works, tol_step, start_mu);
+    else hipLaunchKernelGGL(srbm_k3_ipm_long, dim3(B), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works, tol_step, start_mu);
     if (tm) { HIPCHK(hipEventRecord(h->ev_stop[h->ev_used], h->stream)); h->ev_steps[h->ev_used] = 1; h->ev_used++; }
     hipLaunchKernelGGL(srbm_k4_update, dim3(B), dim3(K4_THREADS), SRBM_DYN_LDS(K4Shared), h->stream, h->dp, h->insts, h->works);
     HIPCHK(hipGetLastError());
@@ -421,7 +367,7 @@ __global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_solve(int n, const do
     dn_trtri(M, n);
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
     dn_solve_inv(0, n, (int)(xv - dbg_smem2), (int)(tv - dbg_smem2)
-#ifdef SRBM_LARGE
+#ifdef SRBM_M_GLOBAL
                  , M
 #endif
     );
@@ -503,7 +449,7 @@ static void free_batch(srbm_batch* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    (void)hipFree(h->dp); (void)hipFree(h->insts); (void)hipFree(h->works);
+    (void)hipFree(h->dp); (void)hipFree(h->dp_co); (void)hipFree(h->insts); (void)hipFree(h->works);
     (void)hipFree(h->d_state); (void)hipFree(h->d_time); (void)hipFree(h->d_ee);
     (void)hipFree(h->d_plant); (void)hipFree(h->d_push_time); (void)hipFree(h->d_push_impulse);
     (void)hipFree(h->d_scratch); (void)hipFree(h->d_wbc); (void)hipHostFree(h->h_stage);
@@ -536,6 +482,16 @@ static int alloc_batch(srbm_batch* h, hipStream_t borrowed_stream) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k1_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(K1Shared)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k2_condense), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(K2Shared)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k4_update), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(K4Shared)));
+#endif
+#ifndef SRBM_LARGE
+    {
+        // the co-resident set: available when the horizon's working set fits half a CU; chosen when the batch has more instances than the GPU has CUs
+        int n_cu = 0;
+        HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
+        h->co_available = srbm_co_configure(h->hp.N, &h->k3_lds_co) == 0;
+        if (h->co_available) HIPCHK(hipMalloc(&h->dp_co, sizeof(SrbmParams)));
+        h->kernel_set = (h->co_available && n_cu > 0 && h->batch > n_cu) ? 1 : 0;
+    }
 #endif
     h->params_dirty = true;
     return 0;
@@ -572,6 +528,7 @@ int srbm_batch_create(srbm_batch** out, int batch, const srbm_mpc_info* info, co
     // 1024 solves) the worst relative primal error is 1.3e-4 at 1e-13, 5e-5 at 1e-14 and 1.4e-5 at 1e-15, for 17.3 / 18.0 /
     // 18.9 IPM iterations per solve.  The parity tolerance of the path is 1e-4.  srbm_set_solver_tolerances overrides.
     p.tol_gap_abs = 1e-15; p.tol_gap_rel = 1e-15; p.tol_feas = 1e-10;
+    p.tol_step = SRBM_DEFAULT_TOL_STEP; p.start_mu = SRBM_DEFAULT_START_MU;      // srbm_set_solver_step_rule
     auto bail = [&]() { free_batch(h); return -1; };
     if (alloc_batch(h, nullptr)) return bail();
     if (hipMemsetAsync(h->works, 0, sizeof(SrbmWork) * (size_t)batch, h->stream) != hipSuccess) { fail("srbm_batch_create: memset failed"); return bail(); }
@@ -591,6 +548,7 @@ int srbm_batch_clone(const srbm_batch* src, srbm_batch** out) {
     h->batch = src->batch; h->device = src->device; h->hp = src->hp; h->push_set = src->push_set;
     auto bail = [&]() { free_batch(h); return -1; };
     if (alloc_batch(h, nullptr)) return bail();
+    h->kernel_set = src->kernel_set;
     const size_t B = h->batch;
     auto cp = [&](void* d, const void* s_, size_t n) { return hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, h->stream) == hipSuccess; };
     bool ok = cp(h->insts, src->insts, sizeof(SrbmInst) * B) && cp(h->works, src->works, sizeof(SrbmWork) * B) &&
@@ -654,6 +612,26 @@ int srbm_set_solver_tolerances(srbm_batch* h, double ga, double gr, double tf, i
     h->params_dirty = true;
     return 0;
 }
+int srbm_set_solver_step_rule(srbm_batch* h, double tol_step, double start_mu) {
+    if (!h || !(tol_step >= 0.0) || !(start_mu >= 0.0)) return fail("bad arguments");
+    h->hp.tol_step = tol_step; h->hp.start_mu = start_mu;
+    h->params_dirty = true;
+    return 0;
+}
+int srbm_set_kernel_set(srbm_batch* h, int which) {
+    if (!h || which < 0 || which > 1) return fail("bad arguments");
+    if (which == 1 && !h->co_available) return fail("srbm_set_kernel_set: the co-resident kernel set is not available for this build / horizon");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->kernel_set = which;
+    return 0;
+}
+int srbm_get_kernel_set(const srbm_batch* h) { return h ? h->kernel_set : -1; }
+int srbm_get_solver_step_rule(const srbm_batch* h, double* tol_step, double* start_mu) {
+    if (!h || !tol_step || !start_mu) return fail("bad arguments");
+    *tol_step = h->hp.tol_step; *start_mu = h->hp.start_mu;
+    return 0;
+}
 int srbm_set_state_trajectory_warm_start(srbm_batch* h, const double* states) {
     if (!h || !states) return fail("bad arguments");
     HIPCHK(hipSetDevice(h->device));
@@ -699,13 +677,20 @@ int srbm_get_real_time_update_dev(srbm_batch* h, const double* state_dev, const 
     HIPCHK(hipMemcpyAsync(h->d_time, time_dev, sizeof(double) * B, hipMemcpyDeviceToDevice, h->stream));
     return launch_step(h);
 }
-static int launch_fused(srbm_batch* h, int first_index, int steps, const SrbmPlantArgs& pl) {
+static int launch_fused(srbm_batch* h, int first_index, int steps, SrbmPlantArgs pl) {
+    pl.tol_step = h->hp.tol_step; pl.start_mu = h->hp.start_mu;
     HIPCHK(hipSetDevice(h->device));
     if (upload_params(h)) return -1;
     if (steps == 0) return 0;
     // one launch for all steps (double time = i*info.integrator_dt, gait_opt_playground.cpp:84, is formed on the device)
     const bool tm = h->timing && h->ev_used < h->ev_start.size();
     if (tm) HIPCHK(hipEventRecord(h->ev_start[h->ev_used], h->stream));
+#ifndef SRBM_LARGE
+    if (h->kernel_set == 1) {
+        if (srbm_co_launch_fused(h->stream, h->dp_co, h->insts, h->works, first_index, steps, h->d_state, h->d_time, h->d_ee, pl, h->batch, h->hp.N, h->k3_lds_co))
+            return fail("launch of the co-resident kernel set failed");
+    } else
+#endif
     if (h->hp.N <= K3_SHORT_N)
         hipLaunchKernelGGL(srbm_rti_fused, dim3(h->batch), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works, first_index, steps,
                            h->d_state, h->d_time, h->d_ee, pl);
@@ -718,7 +703,7 @@ static int launch_fused(srbm_batch* h, int first_index, int steps, const SrbmPla
 }
 int srbm_rti_advance(srbm_batch* h, int first_index, int steps) {
     if (!h || steps < 0) return fail("bad arguments");
-    return launch_fused(h, first_index, steps, SrbmPlantArgs{nullptr, nullptr, nullptr, 1, 0});
+    return launch_fused(h, first_index, steps, SrbmPlantArgs{nullptr, nullptr, nullptr, 1, 0, 0.0, 0.0});
 }
 
 // ---- closed-loop rollout harness (srbm_plant.hiph) ----
@@ -943,6 +928,38 @@ int srbm_gait_compute_gradient(srbm_gait* g) {
     HIPCHK(hipGetLastError());
     return 0;
 }
+// MPCSingleRigidBody::ComputeParamPartialsClarabel (msrb.cpp:642-792) as data: the partials of the QP of the LAST solve of instance `inst` with
+// respect to contact time `idx` of foot `ee`, evaluated on the instance's current trajectory, dense and in the reference's layout
+// (mpc::QPPartials, mpc/include/qp/qp_partials.h:15-35): dA [n_eq][n], dG [n_ineq][n], db [n_eq], dh [n_ineq] (zero as coded).  Debug path like
+// srbm_export_qp: it runs the SAME per-item code the gradient kernel contracts (gait_param_partial_item), with a dense emitter.
+int srbm_gait_get_param_partials(srbm_batch* h, int inst, int ee, int idx, double* dA, double* dG, double* db, double* dh) {
+    if (!h || inst < 0 || inst >= h->batch || ee < 0 || ee >= SRBM_NEE || idx < 0 || !dA || !dG || !db || !dh) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    SrbmInst I;
+    HIPCHK(hipMemcpy(&I, h->insts + inst, sizeof(SrbmInst), hipMemcpyDeviceToHost));
+    const size_t n = I.n, me = I.n_eq, mi = I.n_ineq;
+    if (n == 0 || me == 0) return fail("srbm_gait_get_param_partials: no QP has been solved yet");
+    double* d = nullptr;
+    const size_t tot = me * n + mi * n + me + 1;
+    HIPCHK(hipMalloc(&d, sizeof(double) * tot));
+    int rc = 0;
+    auto done = [&](int r) { (void)hipFree(d); return r; };
+    if (hipMemsetAsync(d, 0, sizeof(double) * tot, h->stream) != hipSuccess) return done(fail("memset failed"));
+    int* derr = reinterpret_cast<int*>(d + me * n + mi * n + me);
+    hipLaunchKernelGGL(srbm_k_gait_param_partials, dim3(1), dim3(KH_THREADS), 0, h->stream, h->dp, h->insts + inst, h->works + inst, ee, idx,
+                       d, d + me * n, d + me * n + mi * n, derr);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return done(fail("srbm_gait_get_param_partials: kernel failed"));
+    int err = 0;
+    if (hipMemcpy(dA, d, sizeof(double) * me * n, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(dG, d + me * n, sizeof(double) * mi * n, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(db, d + me * n + mi * n, sizeof(double) * me, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&err, derr, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+        return done(fail("srbm_gait_get_param_partials: copy failed"));
+    std::memset(dh, 0, sizeof(double) * mi);
+    if (err & SRBM_ERR_CAPACITY) return done(fail("srbm_gait_get_param_partials: contact index out of range"));
+    if (err) return done(fail("srbm_gait_get_param_partials: spline lookup failed (error bits " + std::to_string(err) + ")"));
+    return done(rc);
+}
 int srbm_gait_get_gradient(srbm_gait* g, double* dHdth, int* valid) {
     if (!g || !dHdth) return fail("bad arguments");
     HIPCHK(hipSetDevice(g->h->device));
@@ -974,7 +991,7 @@ int srbm_gait_optimize_contact_times(srbm_gait* g, const double* time) {
     if (upload_params(h)) return -1;
     HIPCHK(hipMemcpyAsync(h->d_time, time, sizeof(double) * (size_t)h->batch, hipMemcpyHostToDevice, h->stream));
     const int threads = h->batch * SRBM_NEE;
-    hipLaunchKernelGGL(srbm_k_gait_lp, dim3((threads + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts, g->xk, g->counts, g->dHdth, h->d_time,
+    hipLaunchKernelGGL(srbm_k_gait_lp, dim3(h->batch), dim3(LP_THREADS), 0, h->stream, h->dp, h->insts, g->xk, g->counts, g->dHdth, h->d_time,
                        g->step, g->pred_red, g->lp_status);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1021,7 +1038,7 @@ static int gait_opt_core(srbm_gait* g) {        // time already in h->d_time
     srbm_batch* h = g->h;
     if (srbm_gait_compute_gradient(g)) return -1;
     const int threads = h->batch * SRBM_NEE;
-    hipLaunchKernelGGL(srbm_k_gait_lp, dim3((threads + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts, g->xk, g->counts, g->dHdth, h->d_time,
+    hipLaunchKernelGGL(srbm_k_gait_lp, dim3(h->batch), dim3(LP_THREADS), 0, h->stream, h->dp, h->insts, g->xk, g->counts, g->dHdth, h->d_time,
                        g->step, g->pred_red, g->lp_status);
     hipLaunchKernelGGL(srbm_k_gait_ready, dim3((h->batch + 63) / 64), dim3(64), 0, h->stream, h->dp, g->valid, g->lp_status, g->ready, -1);
     HIPCHK(hipGetLastError());
@@ -1046,7 +1063,10 @@ int srbm_gait_rti_advance(srbm_gait* g, int first_run_num, int steps, int gait_o
             if (line_search_core(g, true)) return -1;
             hipLaunchKernelGGL(srbm_k_gait_ready, dim3((h->batch + 63) / 64), dim3(64), 0, h->stream, h->dp, g->valid, g->lp_status, g->ready, 0);
         } else if ((run_num + 1) % gait_opt_freq == 0 && run_num > 0) {
-            if (launch_step(h)) return -1;
+            // the solve the gradient differentiates: to the reference's gap criterion (the as-coded KKT sensitivity divides by the slacks, so it
+            // needs the duals Clarabel's tolerance gives); every other solve of the protocol -- plain steps, the 10 candidates of a line
+            // search, which are only compared by cost -- runs with the batch's step rule
+            if (launch_step(h, true)) return -1;
             if (gait_opt_core(g)) return -1;
         } else {
             if (launch_step(h)) return -1;
@@ -1104,6 +1124,14 @@ int srbm_get_kernel_timing(srbm_batch* h, double* total_ms, int* launches) {
     double tot = 0;
     for (size_t i = 0; i < h->ev_used; i++) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, h->ev_start[i], h->ev_stop[i])); tot += ms; }
     *total_ms = tot; *launches = (int)h->ev_used;
+    return 0;
+}
+int srbm_get_kernel_timings(srbm_batch* h, double* ms_each, int max_launches, int* launches) {
+    if (!h || !ms_each || !launches || max_launches < 0) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *launches = (int)h->ev_used;
+    for (size_t i = 0; i < h->ev_used && (int)i < max_launches; i++) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, h->ev_start[i], h->ev_stop[i])); ms_each[i] = ms; }
     return 0;
 }
 int srbm_get_work_counters(srbm_batch* h, double* total_ipm_iterations, double* total_algorithmic_flops) {
@@ -1404,6 +1432,8 @@ int srbm_set_warm_start_trajectory(srbm_batch* h, int first, int count, const sr
         std::memcpy(I.fval, t.force, sizeof(I.fval));
         std::memcpy(I.pval, t.pos_xy, sizeof(I.pval));
         I.init_time = t.init_time;              // init_time_ = trajectory.GetTime(0)
+        I.low_skip = 0; I.low_streak = 0;       // a trajectory from elsewhere: what the solver remembers of this instance's earlier QPs (the back-off of
+                                                // the lower-start attempts, srbm_k3_ipm.hiph) no longer applies
     }
     HIPCHK(hipMemcpy(h->insts + first, v.data(), sizeof(SrbmInst) * (size_t)count, hipMemcpyHostToDevice));
     return 0;
@@ -1427,6 +1457,18 @@ int srbm_trajectory_eval(const srbm_trajectory* t, int ee, double time, double* 
         *in_contact = (kind[lo] == SRBM_K_TD && kind[up] == SRBM_K_LO) ? 1 : 0;
     }
     return err;
+}
+// SingleRigidBodyModel::ConvertManifoldStateToTangentState / ConvertTangentStateToManifoldState (single_rigid_body_model.cpp:188-220; the
+// reference state argument is unused there: quat_ref is the identity): host arithmetic, the functions the kernels use
+int srbm_convert_manifold_to_tangent(const double* state13, double* tangent12) {
+    if (!state13 || !tangent12) return fail("bad arguments");
+    srbm_manifold_to_tangent(state13, tangent12);
+    return 0;
+}
+int srbm_convert_tangent_to_manifold(const double* tangent12, double* state13) {
+    if (!tangent12 || !state13) return fail("bad arguments");
+    srbm_tangent_to_manifold(tangent12, state13);
+    return 0;
 }
 int srbm_eval_trajectory(srbm_batch* h, const double* time, double* force, double* pos, int* in_contact) {
     if (!h || !time) return fail("bad arguments");
@@ -1492,6 +1534,7 @@ __global__ void srbm_k_clear_acc(const SrbmParams* __restrict__ Pp, SrbmInst* __
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= Pp->batch) return;
     insts[b].err_acc = 0; insts[b].n_solves = 0; insts[b].n_not_solved = 0; insts[b].n_maxiter = 0;
+    insts[b].n_low_tried = 0; insts[b].n_low_failed = 0; insts[b].n_step_rule = 0;
 }
 int srbm_clear_status_accumulators(srbm_batch* h) {
     if (!h) return fail("bad arguments");
@@ -1499,6 +1542,14 @@ int srbm_clear_status_accumulators(srbm_batch* h) {
     if (upload_params(h)) return -1;
     hipLaunchKernelGGL(srbm_k_clear_acc, dim3((h->batch + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts);
     HIPCHK(hipGetLastError());
+    return 0;
+}
+int srbm_get_solver_counters(srbm_batch* h, long long* c4) {
+    if (!h || !c4) return fail("bad arguments");
+    std::vector<SrbmInst> v;
+    if (fetch_insts(h, v)) return -1;
+    c4[0] = c4[1] = c4[2] = c4[3] = 0;
+    for (auto& I : v) { c4[0] += I.n_solves; c4[1] += I.n_step_rule; c4[2] += I.n_low_tried; c4[3] += I.n_low_failed; }
     return 0;
 }
 int srbm_result_record_doubles(int N) { return 8 + 12 * (N + 1) + SRBM_NUMAX + 12 * (N + 1) + 6 * SRBM_NSMAX + 16 * (N - 3) + 16 + 36; }

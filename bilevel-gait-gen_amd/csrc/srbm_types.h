@@ -11,6 +11,12 @@
 #include <stdint.h>
 
 #define SRBM_NEE 4
+/* Where the packed normal matrix of the IPM lives: LDS (standard build: one workgroup of 512 threads per CU) or the work record in global
+   memory / L2 (SRBM_M_GLOBAL: the LARGE capacities, whose matrix does not fit the LDS, and the CO-RESIDENT kernel set SRBM_CO -- 256 threads and
+   <= 80 KB of LDS per workgroup, so that TWO instances share a CU and fill each other's latency gaps when the batch exceeds the CU count) */
+#if defined(SRBM_LARGE) || defined(SRBM_CO)
+#define SRBM_M_GLOBAL 1
+#endif
 #define SRBM_KMAX 32          /* knots per foot inside the horizon window */
 #ifdef SRBM_LARGE
 /* The LARGE build of the same sources (libsrbm_rti_large.so): the reference's own limit of 101 trajectory nodes
@@ -54,6 +60,10 @@ typedef struct SrbmParams {
     double Q[144], w[12], Phi[144], Phi_w[12];
     double merit_mu, td_fraction;   /* mpc.cpp:65, :73 */
     double tol_gap_abs, tol_gap_rel, tol_feas;
+    /* (host-side record of srbm_set_solver_step_rule; the kernels receive the two values as launch arguments)  tol_step > 0 ends a solve as soon as the affine (predictor) Newton step -- the distance to the KKT point of
+       the QP as the factor at hand sees it -- is below tol_step * max(1, |u|_inf): the iterate then takes that step and the solve is over;
+       start_mu > 0: every solve is first attempted from Clarabel's starting point with the multipliers scaled to mean(s o lambda) = start_mu */
+    double tol_step, start_mu;
     double legs[SRBM_NEE][4][3];    /* leg geometry for the IK of row f3 (srbm_ik.hiph): joint origins hip / thigh / calf / foot */
     int has_legs, pad2;
 } SrbmParams;
@@ -77,6 +87,10 @@ typedef struct SrbmInst {
     double merit_dd;                              /* directional derivative of the L1 merit along the step of the last solve (mpc.cpp:783-788; the 'Merit dd' column of the statistics log) */
     double acc_mfma;                              /* v_mfma_f64_16x16x4_f64 instructions EXECUTED (per wave) by the condensing and IPM phases: the executed-flop side of the roofline */
     int err_acc, n_solves, n_not_solved, n_maxiter;       /* n_not_solved: status not in {Solved, SolvedInacc}; n_maxiter: of those, MaxIter */
+    int low_streak, last_rule;                            /* last_rule: 1 if the LAST solve ended through the step rule (its duals are then not at the reference's gap tolerance: the
+                                                             gait gradient is marked invalid); low_streak: consecutive failed attempts: the back-off doubles with each (K3_LOW_BACKOFF << streak, at most 48 solves) */
+    int low_skip, n_low_tried, n_low_failed, n_step_rule; /* lower-start attempts (srbm_k3_ipm.hiph): solves left that skip the attempt, attempts, attempts repeated
+                                                             from the standard start; solves ended by the step rule */
 } SrbmInst;
 
 /* per (node, foot) linearisation record */
@@ -127,9 +141,7 @@ typedef struct SrbmWork {
     double x[SRBM_NXMAX];                         /* prev_qp_sol after the line search */
     double z[SRBM_MMAX];                          /* dual vector in the reference's row order */
     double s[SRBM_MMAX];
-#ifdef SRBM_LARGE
-    double Mg[SRBM_HPACK];                        /* LARGE build: the normal matrix / its factor / the inverse of the factor of the IPM (in LDS in the standard build) */
-#endif
+    double Mg[SRBM_HPACK];                        /* SRBM_M_GLOBAL kernels: the normal matrix / its factor / the inverse of the factor of the IPM (in LDS otherwise) */
     double Ms[SRBM_HPACK];                        /* gait step: H + G' diag(lambda/s) G of the last solution (srbm_k3_normal_matrix) */
     double w0[SRBM_MIMAX];                        /* IPM: unit weight of the row/cost-scaled problem, e_r^2 / c (kernel 3 scratch) */
     double prof2[64];                             /* diagnostic builds only: fine-grained stamps (K3_FINE) */
@@ -137,3 +149,11 @@ typedef struct SrbmWork {
     double dbg[4 * 64];
     double dbg2[4 * 32];                          /* diagnostic builds only: worst refinement row (index, s, lambda, e2) */                           /* diagnostic builds only: per-iteration (mu, alpha_aff, alpha, gap_rel) */
 } SrbmWork;
+
+/* launch arguments of the fused RTI kernel (srbm_fused.hiph) besides the batch: the closed-loop mode (plant != nullptr, srbm_plant.hiph) and the two
+   settings of srbm_set_solver_step_rule */
+typedef struct SrbmPlantArgs {
+    double* plant; const double* push_time; const double* push_impulse;
+    int substeps, advance_time;
+    double tol_step, start_mu;
+} SrbmPlantArgs;

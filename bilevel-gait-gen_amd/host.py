@@ -164,8 +164,13 @@ def quat_log3(q):
 
 
 def manifold_to_tangent(s13):
-    s13 = np.asarray(s13, float)
-    return np.concatenate([s13[:6], quat_log3(s13[6:10]), s13[10:13]])
+    """SingleRigidBodyModel::ConvertManifoldStateToTangentState through the library's own host function (srbm_convert_manifold_to_tangent: no GPU
+    needed), so that a Python caller and a C++ caller of the facade hand the MPC the same bits"""
+    a = np.ascontiguousarray(s13, dtype=np.float64)
+    t = np.zeros(12)
+    if lib().srbm_convert_manifold_to_tangent(_d(a), _d(t)) != 0:
+        raise RuntimeError('srbm: ' + lib().srbm_last_error().decode())
+    return t
 
 
 class BatchMPC:
@@ -313,6 +318,26 @@ class BatchMPC:
         a = np.ascontiguousarray(w, dtype=np.float64)
         self._chk(self.L.srbm_set_linear_final_cost(self.h, _d(a)))
 
+    def set_solver_step_rule(self, tol_step, start_mu=0.0):
+        self._chk(self.L.srbm_set_solver_step_rule(self.h, C.c_double(tol_step), C.c_double(start_mu)))
+
+    def set_kernel_set(self, which):
+        """0: one instance per CU (512 threads, M in LDS); 1: two instances per CU (256 threads, M in L2) -- the default follows the batch size"""
+        self._chk(self.L.srbm_set_kernel_set(self.h, int(which)))
+
+    def kernel_set(self):
+        return int(self.L.srbm_get_kernel_set(self.h))
+
+    def solver_step_rule(self):
+        a = C.c_double(0); b = C.c_double(0)
+        self._chk(self.L.srbm_get_solver_step_rule(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def solver_counters(self):
+        c = (C.c_longlong * 4)()
+        self._chk(self.L.srbm_get_solver_counters(self.h, c))
+        return dict(solves=c[0], step_rule=c[1], low_tried=c[2], low_failed=c[3])
+
     def set_state_trajectory_warm_start(self, states):
         a = self._bcast(states, 13)
         self._chk(self.L.srbm_set_state_trajectory_warm_start(self.h, _d(a)))
@@ -449,6 +474,11 @@ class BatchMPC:
         self._chk(self.L.srbm_get_kernel_timing(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def kernel_timings(self, max_launches=64):
+        ms = np.zeros(max_launches); n = C.c_int(0)
+        self._chk(self.L.srbm_get_kernel_timings(self.h, _d(ms), int(max_launches), C.byref(n)))
+        return ms[:min(n.value, max_launches)].copy()
+
     def work_counters(self):
         it = C.c_double(0); fl = C.c_double(0)
         self._chk(self.L.srbm_get_work_counters(self.h, C.byref(it), C.byref(fl)))
@@ -520,6 +550,15 @@ class BatchMPC:
         A = np.zeros((m, n)); b = np.zeros(m); P = np.zeros((n, n)); q = np.zeros(n)
         self._chk(self.L.srbm_export_qp(self.h, int(inst), _d(A), _d(b), _d(P), _d(q)))
         return A, b, P, q
+
+    def param_partials(self, inst, ee, idx):
+        """MPCSingleRigidBody::ComputeParamPartialsClarabel (mpc_single_rigid_body.cpp:642-792) as dense matrices: (dA, dG, db, dh) of the QP
+        of the last solve w.r.t. contact time `idx` of foot `ee`, evaluated on the current trajectory of instance `inst`."""
+        sz = self.sizes()[inst]
+        n, me, mi = int(sz[0]), int(sz[2]), int(sz[3])
+        dA = np.zeros((me, n)); dG = np.zeros((mi, n)); db = np.zeros(me); dh = np.zeros(mi)
+        self._chk(self.L.srbm_gait_get_param_partials(self.h, int(inst), int(ee), int(idx), _d(dA), _d(dG), _d(db), _d(dh)))
+        return dA, dG, db, dh
 
 
 class BatchGaitOptimizer:

@@ -1,7 +1,6 @@
 // The reference's classes downstream of the MPC over the C-ABI of include/srbm_rti.h, with the
 // reference's names and signatures, for a caller that holds them by value as controllers/include/mpc_controller.h does:
-//   mpc::SingleRigidBodyModel    /root/reference/mpc/include/models/single_rigid_body_model.h:30-70: the kinematics entry points the
-//                                controller calls -- InverseKinematics, GetEndEffectorLocations, GetMass, GetIrInv
+//   mpc::SingleRigidBodyModel    lives in mpc_facade/mpc.h (MPCSingleRigidBody::GetModelCopy returns one by value)
 //   controller::QPControl        /root/reference/controllers/include/qp_control.h:52-88 with the target setters of its base class
 //                                (controllers/include/controller.h:52-54): the 1 kHz whole-body QP
 // Each object owns a batch of ONE instance of the library (the kinematics / whole-body entries do not touch the MPC state of a batch);
@@ -13,85 +12,6 @@
 
 #include "mpc.h"
 
-namespace mpc {
-
-class SingleRigidBodyModel {
-public:
-    SingleRigidBodyModel(const std::string& robot_urdf, const std::vector<std::string>& frames, int discretization_steps, double dt, const vector_t& nom_state)
-        : frames_(frames), discretization_steps_(discretization_steps), dt_(dt), consts_(ModelConstantsFromUrdf(robot_urdf, ToStdVec(nom_state))),
-          legs_(LegKinematicsFromUrdf(robot_urdf)) { Create(); }
-    SingleRigidBodyModel(const SingleRigidBodyModel& o) : frames_(o.frames_), discretization_steps_(o.discretization_steps_), dt_(o.dt_), consts_(o.consts_), legs_(o.legs_) { Create(); }
-    SingleRigidBodyModel& operator=(const SingleRigidBodyModel& o) {
-        if (this == &o) return *this;
-        Release();
-        frames_ = o.frames_; discretization_steps_ = o.discretization_steps_; dt_ = o.dt_; consts_ = o.consts_; legs_ = o.legs_;
-        Create();
-        return *this;
-    }
-    ~SingleRigidBodyModel() { Release(); }
-
-    // single_rigid_body_model.cpp:314-425.  state: manifold SRBM state (13); state_guess: full configuration (19), its joint part is the
-    // initial guess.  The joint limits are accepted and ignored, as the reference does (its clamp is commented out, :407-414).
-    vector_t InverseKinematics(const vector_t& state, const std::vector<vector_3t>& end_effector_location, const vector_t& state_guess,
-                               const vector_t& /*joint_limits_ub*/, const vector_t& /*joint_limits_lb*/) {
-        if (state.size() != 13 || state_guess.size() != 19 || end_effector_location.size() != 4) throw std::runtime_error("InverseKinematics: wrong sizes.");
-        double s[13], e[12], g[19], q[19]; int status = 0;
-        for (int i = 0; i < 13; i++) s[i] = state(i);
-        for (int i = 0; i < 19; i++) g[i] = state_guess(i);
-        for (int ee = 0; ee < 4; ee++) for (int c = 0; c < 3; c++) e[3 * ee + c] = end_effector_location[ee](c);
-        check_srbm(srbm_inverse_kinematics(h_, s, e, g, q, nullptr, &status));
-        if (status) {
-            std::cerr << "IK did not converge." << std::endl;
-            throw std::runtime_error("IK did not converge.");
-        }
-        vector_t out(19);
-        for (int i = 0; i < 19; i++) out(i) = q[i];
-        return out;
-    }
-    // single_rigid_body_model.cpp:443-455
-    std::vector<vector_3t> GetEndEffectorLocations(const vector_t& q) {
-        if (q.size() != 19) throw std::runtime_error("GetEndEffectorLocations: wrong size.");
-        double qq[19], e[12];
-        for (int i = 0; i < 19; i++) qq[i] = q(i);
-        check_srbm(srbm_forward_kinematics(h_, qq, e));
-        std::vector<vector_3t> out(4);
-        for (int ee = 0; ee < 4; ee++) for (int c = 0; c < 3; c++) out[ee](c) = e[3 * ee + c];
-        return out;
-    }
-    double GetMass() const { return consts_.mass; }
-    matrix_t GetIrInv() const {                                  // single_rigid_body_model.cpp:33-37 (Ir_inv_)
-        const double* a = consts_.Ir;
-        const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
-        matrix_t r = matrix_t::Zero(3, 3);
-        r(0, 0) = (a[4] * a[8] - a[5] * a[7]) / det; r(0, 1) = (a[2] * a[7] - a[1] * a[8]) / det; r(0, 2) = (a[1] * a[5] - a[2] * a[4]) / det;
-        r(1, 0) = (a[5] * a[6] - a[3] * a[8]) / det; r(1, 1) = (a[0] * a[8] - a[2] * a[6]) / det; r(1, 2) = (a[2] * a[3] - a[0] * a[5]) / det;
-        r(2, 0) = (a[3] * a[7] - a[4] * a[6]) / det; r(2, 1) = (a[1] * a[6] - a[0] * a[7]) / det; r(2, 2) = (a[0] * a[4] - a[1] * a[3]) / det;
-        return r;
-    }
-    int GetNumManifoldStates() const { return 13; }
-    int GetNumTangentStates() const { return 12; }
-    int GetNumEndEffectors() const { return 4; }
-    const srbm_leg_kinematics& LegKinematics() const { return legs_; }
-
-private:
-    static std::vector<double> ToStdVec(const vector_t& v) { std::vector<double> r(v.size()); for (int i = 0; i < (int)v.size(); i++) r[i] = v(i); return r; }
-    void Create() {
-        srbm_mpc_info ci{};
-        ci.num_nodes = 10; ci.integrator_dt = dt_ > 0 ? dt_ : 0.05; ci.friction_coef = 0.5; ci.force_bound = 100; ci.swing_height = 0.1; ci.foot_offset = 0;
-        ci.ee_box_size[0] = ci.ee_box_size[1] = 0.1; ci.force_cost = 0;
-        check_srbm(srbm_batch_create(&h_, 1, &ci, &consts_, 0));
-        if (srbm_set_leg_kinematics(h_, &legs_)) { const std::string m = srbm_last_error(); Release(); throw std::runtime_error(m); }
-    }
-    void Release() { if (h_) srbm_batch_destroy(h_); h_ = nullptr; }
-    std::vector<std::string> frames_;
-    int discretization_steps_ = 1;
-    double dt_ = 0.05;
-    srbm_model consts_{};
-    srbm_leg_kinematics legs_{};
-    srbm_batch* h_ = nullptr;
-};
-
-}  // namespace mpc
 
 namespace controller {
 

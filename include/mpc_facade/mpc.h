@@ -17,6 +17,7 @@
 // Eigen: the real <Eigen/Core> when it exists, else mpc_facade/eigen_shim.h (this container has none).
 #pragma once
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <fstream>
 #include <iomanip>
@@ -56,6 +57,7 @@ using vector_t = Eigen::VectorXd;
 using matrix_t = Eigen::MatrixXd;
 using vector_3t = Eigen::Vector3d;
 using vector_2t = Eigen::Vector2d;
+using matrix_33t = Eigen::Matrix3d;
 
 enum MPCVerbosityLevel { Nothing = 0, Timing = 1, Optimization = 2, All = 3 };
 enum Gaits { Trot = 0, Amble = 1, Static_Walk = 2 };
@@ -159,10 +161,42 @@ private:
 class MPCSingleRigidBody;
 
 // mpc/include/qp/qp_partials.h:15-57.  The reference fills these with 260x372 / 752x372 matrices on the host and contracts them in
-// GaitOptimizer::ComputeCostFcnDerivWrtContactTimes; here the contraction is fused on the device (srbm_gait_compute_gradient) and
-// the objects only carry which MPC they belong to.
-struct QPPartials { const MPCSingleRigidBody* owner = nullptr; int ee = -1, idx = -1; void SetZero() {} };
-struct QPPartialsDense { MPCSingleRigidBody* owner = nullptr; bool modified = false; void SetZero() { modified = false; } };
+// GaitOptimizer::ComputeCostFcnDerivWrtContactTimes; here the contraction is fused on the device (srbm_gait_compute_gradient), which is what
+// GaitOptimizer uses.  The members are still DATA for a caller that reads them (test/mpc_test.cpp:181-184): ComputeParamPartialsClarabel fills
+// dA, dG, db, dh from the device (srbm_gait_get_param_partials: the same entries the fused gradient contracts), GetQPPartials fills the rank-2 QP
+// partials of clarabel_interface.cpp:180-260 -- unless MPCSingleRigidBody::SetPartialsAsData(false) asked for handles only (a facade extension for
+// callers like MPCController::GaitOpt that never read them).  Dense matrices where the reference has Eigen::SparseMatrix (`dA += partials.dA`
+// reads the same); dP, dl, du, dq of the parameter partials stay empty as they do in the reference.
+struct QPPartials {
+    matrix_t dA, dP, dG;
+    vector_t dl, du, dq, db, dh;
+    const MPCSingleRigidBody* owner = nullptr; int ee = -1, idx = -1;
+    void SetZero() { dP.setZero(); dA.setZero(); dG.setZero(); dq.setZero(); dl.setZero(); du.setZero(); db.setZero(); dh.setZero(); }
+};
+struct QPPartialsDense {
+    matrix_t dA, dP, dG;
+    vector_t dl, du, dq, db, dh;
+    MPCSingleRigidBody* owner = nullptr; bool modified = false;
+    void SetZero() { dP.setZero(); dA.setZero(); dG.setZero(); dq.setZero(); dl.setZero(); du.setZero(); db.setZero(); dh.setZero(); modified = false; }
+};
+
+// mpc/include/qp/qp_data.h:60-135: what callers read of the QP of the last solve (test/mpc_test.cpp:125-160, test/gait_opt_playground.cpp:119-130),
+// in the Clarabel form the live path uses (qp_data.cpp:195-300 with using_clarabel_): A x + s = ub_, rows in constraint order -- dynamics, force
+// box, friction cone, foot box, touch-down rows, start rows; lb_ stays zero.  Dense where the reference holds Eigen::SparseMatrix.  Filled by
+// MPCSingleRigidBody::GetQPData from srbm_export_qp (a read-back path: the device never forms these matrices).
+struct QPData {
+    matrix_t sparse_constraint_, sparse_cost_;
+    vector_t lb_, ub_, cost_linear;
+    int num_dynamics_constraints = 0, num_decision_vars = 0;
+    int num_cone_constraints_ = 0, num_box_constraints_ = 0, num_fk_constraints_ = 0, num_force_box_constraints_ = 0, num_fk_ineq_constraints_ = 0,
+        num_ee_location_constraints_ = 0, num_start_ee_constraints_ = 0, num_td_pos_constraints_ = 0, num_raibert_constraints_ = 0;
+    bool using_clarabel_ = true;
+    int num_equality_ = 0, num_inequality_ = 0;
+    int GetTotalNumConstraints() const {            // qp_data.cpp:61-100 for the constraint list of the SRBM MPC (msrb.cpp:13-20)
+        return num_dynamics_constraints + num_force_box_constraints_ + num_cone_constraints_ + num_ee_location_constraints_ + num_td_pos_constraints_ +
+               num_raibert_constraints_ + num_start_ee_constraints_;
+    }
+};
 
 // what MPC::GetModel() hands out (mpc/include/models/model.h): the two getters the caller uses (mpc_controller.cpp:232,239)
 class Model {
@@ -175,11 +209,121 @@ private:
     double mass_;
 };
 
+// mpc/include/models/single_rigid_body_model.h:28-100: the entry points callers of the MPC use -- kinematics (InverseKinematics,
+// GetEndEffectorLocations), the manifold <-> tangent maps (controllers/mpc_controller.cpp:60), GetIr / GetIrInv / GetMass (:258, qp_control).
+// Owns a batch of ONE instance of the library (the kinematics entries do not touch the MPC state of a batch).
+class SingleRigidBodyModel {
+public:
+    SingleRigidBodyModel(const std::string& robot_urdf, const std::vector<std::string>& frames, int discretization_steps, double dt, const vector_t& nom_state)
+        : frames_(frames), discretization_steps_(discretization_steps), dt_(dt), consts_(ModelConstantsFromUrdf(robot_urdf, ToStdVec(nom_state))),
+          legs_(LegKinematicsFromUrdf(robot_urdf)) { Create(); }
+    SingleRigidBodyModel(const srbm_model& consts, const srbm_leg_kinematics& legs, double dt) : dt_(dt), consts_(consts), legs_(legs) { Create(); }
+    SingleRigidBodyModel(const SingleRigidBodyModel& o) : frames_(o.frames_), discretization_steps_(o.discretization_steps_), dt_(o.dt_), consts_(o.consts_), legs_(o.legs_) { Create(); }
+    SingleRigidBodyModel& operator=(const SingleRigidBodyModel& o) {
+        if (this == &o) return *this;
+        Release();
+        frames_ = o.frames_; discretization_steps_ = o.discretization_steps_; dt_ = o.dt_; consts_ = o.consts_; legs_ = o.legs_;
+        Create();
+        return *this;
+    }
+    ~SingleRigidBodyModel() { Release(); }
+
+    // single_rigid_body_model.cpp:314-425.  state: manifold SRBM state (13); state_guess: full configuration (19), its joint part is the
+    // initial guess.  The joint limits are accepted and ignored, as the reference does (its clamp is commented out, :407-414).
+    vector_t InverseKinematics(const vector_t& state, const std::vector<vector_3t>& end_effector_location, const vector_t& state_guess,
+                               const vector_t& /*joint_limits_ub*/, const vector_t& /*joint_limits_lb*/) {
+        if (state.size() != 13 || state_guess.size() != 19 || end_effector_location.size() != 4) throw std::runtime_error("InverseKinematics: wrong sizes.");
+        double s[13], e[12], g[19], q[19]; int status = 0;
+        for (int i = 0; i < 13; i++) s[i] = state(i);
+        for (int i = 0; i < 19; i++) g[i] = state_guess(i);
+        for (int ee = 0; ee < 4; ee++) for (int c = 0; c < 3; c++) e[3 * ee + c] = end_effector_location[ee](c);
+        check_srbm(srbm_inverse_kinematics(h_, s, e, g, q, nullptr, &status));
+        if (status) {
+            std::cerr << "IK did not converge." << std::endl;
+            throw std::runtime_error("IK did not converge.");
+        }
+        vector_t out(19);
+        for (int i = 0; i < 19; i++) out(i) = q[i];
+        return out;
+    }
+    // single_rigid_body_model.cpp:443-455
+    std::vector<vector_3t> GetEndEffectorLocations(const vector_t& q) {
+        if (q.size() != 19) throw std::runtime_error("GetEndEffectorLocations: wrong size.");
+        double qq[19], e[12];
+        for (int i = 0; i < 19; i++) qq[i] = q(i);
+        check_srbm(srbm_forward_kinematics(h_, qq, e));
+        std::vector<vector_3t> out(4);
+        for (int ee = 0; ee < 4; ee++) for (int c = 0; c < 3; c++) out[ee](c) = e[3 * ee + c];
+        return out;
+    }
+    double GetMass() const { return consts_.mass; }
+    matrix_t GetIrInv() const {                                  // single_rigid_body_model.cpp:33-37 (Ir_inv_)
+        const double* a = consts_.Ir;
+        const double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+        matrix_t r = matrix_t::Zero(3, 3);
+        r(0, 0) = (a[4] * a[8] - a[5] * a[7]) / det; r(0, 1) = (a[2] * a[7] - a[1] * a[8]) / det; r(0, 2) = (a[1] * a[5] - a[2] * a[4]) / det;
+        r(1, 0) = (a[5] * a[6] - a[3] * a[8]) / det; r(1, 1) = (a[0] * a[8] - a[2] * a[6]) / det; r(1, 2) = (a[2] * a[3] - a[0] * a[5]) / det;
+        r(2, 0) = (a[3] * a[7] - a[4] * a[6]) / det; r(2, 1) = (a[1] * a[6] - a[0] * a[7]) / det; r(2, 2) = (a[0] * a[4] - a[1] * a[3]) / det;
+        return r;
+    }
+    matrix_33t GetIr() const {                                   // single_rigid_body_model.h:81; used at controllers/mpc_controller.cpp:258
+        matrix_33t r;
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r(i, j) = consts_.Ir[3 * i + j];
+        return r;
+    }
+    // single_rigid_body_model.cpp:179-220 (ref_state is unused there: quat_ref is the identity); controllers/mpc_controller.cpp:60
+    static vector_3t ConvertManifoldToTangentQuat(const Eigen::Vector4d& state, const Eigen::Vector4d& /*ref_state*/) {
+        double s[13] = {0}, t[12];
+        for (int i = 0; i < 4; i++) s[6 + i] = state(i);
+        check_srbm(srbm_convert_manifold_to_tangent(s, t));
+        vector_3t r;
+        for (int i = 0; i < 3; i++) r(i) = t[6 + i];
+        return r;
+    }
+    vector_t ConvertManifoldStateToTangentState(const vector_t& state, const vector_t& ref_state) const {
+        if (state.size() != 13 || ref_state.size() != 13) throw std::runtime_error("ConvertManifoldStateToTangentState: 13-entry states expected.");
+        vector_t t(12);
+        check_srbm(srbm_convert_manifold_to_tangent(state.data(), t.data()));
+        return t;
+    }
+    vector_t ConvertTangentStateToManifoldState(const vector_t& state, const vector_t& /*ref_state*/) const {
+        if (state.size() != 12) throw std::runtime_error("ConvertTangentStateToManifoldState: a 12-entry tangent state expected.");
+        vector_t s(13);
+        check_srbm(srbm_convert_tangent_to_manifold(state.data(), s.data()));
+        return s;
+    }
+    vector_3t GetCOMPosition(const vector_t& state) const { vector_3t p; for (int i = 0; i < 3; i++) p(i) = state(i); return p; }
+    vector_2t GetCOMHipOffset(int ee) const { vector_2t r; r(0) = consts_.hip_xy[2 * ee]; r(1) = consts_.hip_xy[2 * ee + 1]; return r; }   // (the box centres of the MPC add the offsets of GetCOMToHip, srbm_get_ee_box_center)
+    int GetNumManifoldStates() const { return 13; }
+    int GetNumTangentStates() const { return 12; }
+    int GetNumEndEffectors() const { return 4; }
+    static constexpr int QUAT_SIZE = 4, QUAT_START = 6, ORIENTATION_START = 6, ANG_VEL_START = 9, LIN_MOM_START = 3, POS_START = 0;
+    const srbm_leg_kinematics& LegKinematics() const { return legs_; }
+
+private:
+    static std::vector<double> ToStdVec(const vector_t& v) { std::vector<double> r(v.size()); for (int i = 0; i < (int)v.size(); i++) r[i] = v(i); return r; }
+    void Create() {
+        srbm_mpc_info ci{};
+        ci.num_nodes = 10; ci.integrator_dt = dt_ > 0 ? dt_ : 0.05; ci.friction_coef = 0.5; ci.force_bound = 100; ci.swing_height = 0.1; ci.foot_offset = 0;
+        ci.ee_box_size[0] = ci.ee_box_size[1] = 0.1; ci.force_cost = 0;
+        check_srbm(srbm_batch_create(&h_, 1, &ci, &consts_, 0));
+        if (srbm_set_leg_kinematics(h_, &legs_)) { const std::string m = srbm_last_error(); Release(); throw std::runtime_error(m); }
+    }
+    void Release() { if (h_) srbm_batch_destroy(h_); h_ = nullptr; }
+    std::vector<std::string> frames_;
+    int discretization_steps_ = 1;
+    double dt_ = 0.05;
+    srbm_model consts_{};
+    srbm_leg_kinematics legs_{};
+    srbm_batch* h_ = nullptr;
+};
+
+
 // mpc/include/mpc.h:70-170 + mpc/include/mpc_single_rigid_body.h:11-76
 class MPCSingleRigidBody {
 public:
     MPCSingleRigidBody(const MPCInfo& info, const std::string& robot_urdf)
-        : MPCSingleRigidBody(info, ModelConstantsFromUrdf(robot_urdf, ToStd(info.nom_state))) {}
+        : MPCSingleRigidBody(info, ModelConstantsFromUrdf(robot_urdf, ToStd(info.nom_state))) { legs_ = LegKinematicsFromUrdf(robot_urdf); has_legs_ = true; }
     // the same object from constants computed elsewhere (e.g. by pinocchio in a build that has it)
     MPCSingleRigidBody(const MPCInfo& info, const srbm_model& model) : info_(info), model_consts_(model), model_(model.mass) {
         srbm_mpc_info ci{};
@@ -187,16 +331,22 @@ public:
         ci.force_bound = info.force_bound; ci.swing_height = info.swing_height; ci.foot_offset = info.foot_offset;
         ci.ee_box_size[0] = info.ee_box_size(0); ci.ee_box_size[1] = info.ee_box_size(1); ci.force_cost = info.force_cost;
         check_srbm(srbm_batch_create(&h_, 1, &ci, &model_consts_, 0));
+        // the single-instance drop-in keeps ClarabelInterface's criterion (gap 1e-15) for every solve: any of them may be differentiated next
+        // (ComputeDerivativeTerms).  SetSolverStepRule opts into the library's faster termination (srbm_set_solver_step_rule).
+        check_srbm(srbm_set_solver_step_rule(h_, 0.0, 0.0));
     }
+    void SetSolverStepRule(double tol_step, double start_mu) { check_srbm(srbm_set_solver_step_rule(h_, tol_step, start_mu)); }
     // value semantics (mpc.cpp:1133-1181, mpc_single_rigid_body.cpp:804-807)
     MPCSingleRigidBody(const MPCSingleRigidBody& other) : info_(other.info_), model_consts_(other.model_consts_), model_(other.model_),
-                                                          used_log_file_(other.used_log_file_), solves_(other.solves_) {
+                                                          used_log_file_(other.used_log_file_), solves_(other.solves_), last_solve_ms_(other.last_solve_ms_),
+                                                          partials_as_data_(other.partials_as_data_), legs_(other.legs_), has_legs_(other.has_legs_) {
         check_srbm(srbm_batch_clone(other.h_, &h_));
     }
     MPCSingleRigidBody& operator=(const MPCSingleRigidBody& other) {
         if (this == &other) return *this;
         Release();
         info_ = other.info_; model_consts_ = other.model_consts_; model_ = other.model_; used_log_file_ = other.used_log_file_; solves_ = other.solves_;
+        last_solve_ms_ = other.last_solve_ms_; partials_as_data_ = other.partials_as_data_; legs_ = other.legs_; has_legs_ = other.has_legs_; kin_.reset();
         check_srbm(srbm_batch_clone(other.h_, &h_));
         return *this;
     }
@@ -247,7 +397,9 @@ public:
         double ee[12];
         PackEE(ee_start_locations, ee);
         CheckState(state);
+        const auto t0 = std::chrono::steady_clock::now();
         check_srbm(srbm_create_initial_run(h_, state.data(), ee));
+        last_solve_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / 10;
         solves_ += 10;
         return GetTrajectory();
     }
@@ -258,7 +410,9 @@ public:
         double ee[12];
         PackEE(ee_start_locations, ee);
         CheckState(state);
+        const auto t0 = std::chrono::steady_clock::now();
         check_srbm(srbm_get_real_time_update(h_, state.data(), &init_time, ee));
+        last_solve_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();      // utils::Timer around Solve, msrb.cpp:27,179
         solves_ += 1;
         int st = 0, err = 0;
         check_srbm(srbm_get_status(h_, &st, &err));
@@ -290,11 +444,55 @@ public:
     int GetNode(double time) const { return GetTrajectory().GetNode(time); }                             // mpc.cpp:1027-1029
     vector_t GetQPSolution() const {
         const int n = GetNumDecisionVars();
-        std::vector<double> x((info_.num_nodes + 1) * 12 + 160);
+        std::vector<double> x(MaxDecisionVars());
         check_srbm(srbm_get_qp_solution(h_, x.data(), (int)x.size()));
         vector_t v(n);
         for (int i = 0; i < n; i++) v(i) = x[i];
         return v;
+    }
+    double GetModifiedCost(int /*num_nodes*/) const { return GetCost(); }                                // msrb.cpp:798-802 (the truncation is commented out there)
+    vector_t GetTargetConfig(double time) const {                                                        // mpc.cpp:708-711: states.at(node).tail(num_states_ - 5), num_states_ = 12
+        const Trajectory t = GetTrajectory();
+        const int node = (int)std::floor((time - t.Record().init_time) / info_.integrator_dt);
+        return t.GetState(node).tail(7);
+    }
+    vector_t GetForceTarget(double time) const {                                                         // mpc.cpp:713-724
+        const Trajectory t = GetTrajectory();
+        const controller::Contact contacts = t.GetDesiredContacts(time);
+        vector_t forces(contacts.GetNumContacts() * 3);
+        int idx = 0;
+        for (int ee = 0; ee < 4; ee++)
+            if (contacts.in_contact_.at(ee)) { const Eigen::Vector3d f = t.GetForce(ee, time); for (int c = 0; c < 3; c++) forces(idx + c) = f(c); idx += 3; }
+        return forces;
+    }
+    // msrb.cpp:477-500: inverse kinematics of the trajectory's node state and foot locations at `time`; prev_state (19) is the guess
+    vector_t GetFullTargetState(double time, const vector_t& prev_state) {
+        const Trajectory t = GetTrajectory();
+        std::vector<vector_3t> ee_locations(4);
+        for (int ee = 0; ee < 4; ee++) ee_locations.at(ee) = t.GetEndEffectorLocation(ee, time);
+        return KinModel().InverseKinematics(t.GetState(t.GetNode(time)), ee_locations, prev_state, info_.joint_bounds_ub, info_.joint_bounds_lb);
+    }
+    SingleRigidBodyModel GetModelCopy() const { return KinModel(); }                                     // msrb.cpp:1060-1062
+    // the leg geometry of a model built from constants (the URDF constructor reads it from the file)
+    void SetLegKinematics(const srbm_leg_kinematics& legs) { legs_ = legs; has_legs_ = true; kin_.reset(); }
+    const QPData& GetQPData() const {                                                                    // mpc.cpp:1097-1099
+        const std::array<int, 8> sz = Sizes();
+        const int n = sz[0], mrows = sz[1], ns = sz[7];
+        QPData& d = qp_data_;
+        d.num_decision_vars = n; d.num_dynamics_constraints = (info_.num_nodes + 1) * 12;
+        d.num_force_box_constraints_ = 2 * ns; d.num_cone_constraints_ = 4 * ns; d.num_ee_location_constraints_ = 16 * (info_.num_nodes - 3);
+        d.num_td_pos_constraints_ = sz[6]; d.num_start_ee_constraints_ = 8; d.num_raibert_constraints_ = 0;
+        d.num_equality_ = sz[2]; d.num_inequality_ = sz[3];
+        if (n == 0) return d;                                             // nothing solved yet
+        std::vector<double> A((size_t)mrows * n), b(mrows), P((size_t)n * n), q(n);
+        check_srbm(srbm_export_qp(h_, 0, A.data(), b.data(), P.data(), q.data()));
+        d.sparse_constraint_ = matrix_t::Zero(mrows, n); d.sparse_cost_ = matrix_t::Zero(n, n);
+        for (int r = 0; r < mrows; r++) for (int c = 0; c < n; c++) d.sparse_constraint_(r, c) = A[(size_t)r * n + c];
+        for (int r = 0; r < n; r++) for (int c = 0; c < n; c++) d.sparse_cost_(r, c) = P[(size_t)r * n + c];
+        d.ub_ = vector_t(mrows); d.lb_ = vector_t::Zero(mrows); d.cost_linear = vector_t(n);
+        for (int r = 0; r < mrows; r++) d.ub_(r) = b[r];
+        for (int c = 0; c < n; c++) d.cost_linear(c) = q[c];
+        return d;
     }
     controller::Contact GetDesiredContacts(double time) const { return GetTrajectory().GetDesiredContacts(time); }
     std::vector<Eigen::Vector2d> GetEEBoxCenter() {                                                      // msrb.cpp:502-509
@@ -325,9 +523,26 @@ public:
     bool GetQPPartials(QPPartialsDense& partials) const {                                                // mpc.cpp:1058-1069
         if (GetSolveQuality() != Solved) return false;
         partials.owner = const_cast<MPCSingleRigidBody*>(this); partials.modified = false;
+        if (partials_as_data_) FillQPPartials(partials);
         return true;
     }
-    bool ComputeParamPartialsClarabel(const Trajectory&, QPPartials& partials, int ee, int idx) { partials.owner = this; partials.ee = ee; partials.idx = idx; return true; }
+    // msrb.cpp:642-792.  The partials are evaluated on the MPC's CURRENT trajectory (every caller passes mpc.GetTrajectory() or the trajectory the
+    // MPC still holds: mpc_controller.cpp:535-545, test/gait_opt_playground.cpp:36-41, test/mpc_test.cpp:121-182 before the update)
+    bool ComputeParamPartialsClarabel(const Trajectory&, QPPartials& partials, int ee, int idx) {
+        partials.owner = this; partials.ee = ee; partials.idx = idx;
+        if (partials_as_data_) {
+            const std::array<int, 8> sz = Sizes();
+            const int n = sz[0], me = sz[2], mi = sz[3];
+            std::vector<double> dA((size_t)me * n), dG((size_t)mi * n), db(me), dh(mi);
+            check_srbm(srbm_gait_get_param_partials(h_, 0, ee, idx, dA.data(), dG.data(), db.data(), dh.data()));
+            partials.dA = matrix_t::Zero(me, n); partials.dG = matrix_t::Zero(mi, n); partials.db = vector_t(me); partials.dh = vector_t(mi);
+            for (int r = 0; r < me; r++) { partials.db(r) = db[r]; for (int c = 0; c < n; c++) partials.dA(r, c) = dA[(size_t)r * n + c]; }
+            for (int r = 0; r < mi; r++) { partials.dh(r) = dh[r]; for (int c = 0; c < n; c++) partials.dG(r, c) = dG[(size_t)r * n + c]; }
+        }
+        return true;
+    }
+    // facade extension: false = QPPartials / QPPartialsDense are handles (no read-back from the device); the fused gradient does not need them
+    void SetPartialsAsData(bool as_data) { partials_as_data_ = as_data; }
     srbm_gait* Gait() { if (!gait_) check_srbm(srbm_gait_create(h_, &gait_)); return gait_; }
     srbm_batch* Handle() const { return h_; }
     const MPCInfo& Info() const { return info_; }
@@ -348,6 +563,33 @@ private:
     }
     static void CheckState(const vector_t& s) { if (s.size() != 13) throw std::runtime_error("The SRBM state has 13 entries."); }
     std::array<int, 8> Sizes() const { std::array<int, 8> s{}; check_srbm(srbm_get_sizes(h_, s.data())); return s; }
+    int MaxDecisionVars() const { int cap[4]; check_srbm(srbm_get_capacity(cap)); return (info_.num_nodes + 1) * 12 + cap[1]; }     // either build of the library
+    SingleRigidBodyModel& KinModel() const {
+        if (!has_legs_) throw std::runtime_error("The leg kinematics are not known: construct the MPC from a URDF or call SetLegKinematics.");
+        if (!kin_) kin_ = std::make_shared<SingleRigidBodyModel>(model_consts_, legs_, info_.integrator_dt);
+        return *kin_;
+    }
+    // the rank-2 QP partials of ClarabelInterface::CalcDerivativeWrtMats / Vecs (clarabel_interface.cpp:180-260) from the device's sensitivity
+    // d = [dz; dlam; dnu], the raw minimiser and the duals
+    void FillQPPartials(QPPartialsDense& p) const {
+        const std::array<int, 8> sz = Sizes();
+        const int n = sz[0], mrows = sz[1], me = sz[2], mi = sz[3], nxs = (info_.num_nodes + 1) * 12;
+        int cap[4]; check_srbm(srbm_get_capacity(cap));
+        const int ldx = nxs + cap[1], ldz = nxs + 6 * cap[2] + 16 * (info_.num_nodes - 3) + 16, ldd = ldx + ldz;
+        std::vector<double> x(ldx), z(ldz), s(ldz), d(ldd);
+        check_srbm(srbm_get_raw_qp_minimiser(h_, x.data(), ldx));
+        check_srbm(srbm_get_dual_solution(h_, z.data(), s.data(), ldz));
+        check_srbm(srbm_gait_get_sensitivity(const_cast<MPCSingleRigidBody*>(this)->Gait(), d.data(), ldd));
+        const double* dz = d.data(); const double* dlam = dz + n; const double* dnu = dlam + mi;
+        auto nu = [&](int r) { return r < nxs ? z[r] : z[mi + r]; };          // dual vector in row order: dynamics, inequalities, touch-down + start rows
+        const double* lam = z.data() + nxs;
+        (void)mrows;
+        p.dA = matrix_t::Zero(me, n); p.dG = matrix_t::Zero(mi, n);
+        p.dq = vector_t(n); p.db = vector_t(me); p.dh = vector_t(mi);
+        for (int c = 0; c < n; c++) p.dq(c) = dz[c];
+        for (int r = 0; r < me; r++) { p.db(r) = -dnu[r]; for (int c = 0; c < n; c++) p.dA(r, c) = dnu[r] * x[c] + nu(r) * dz[c]; }
+        for (int r = 0; r < mi; r++) { p.dh(r) = -lam[r] * dlam[r]; for (int c = 0; c < n; c++) p.dG(r, c) = lam[r] * dlam[r] * x[c] + lam[r] * dz[c]; }
+    }
     void Release() {
         if (gait_) { srbm_gait_destroy(gait_); gait_ = nullptr; }
         if (h_) { srbm_batch_destroy(h_); h_ = nullptr; }
@@ -371,15 +613,16 @@ private:
     }
     void PrintLine(std::ostream& os, bool with_header) const {
         if (with_header) PrintHeader(os);
-        double st[8], merit = 0, merit_dd = 0, qpc = 0;
+        double st[8], merit = 0, merit_dd = 0;
         check_srbm(srbm_get_stats(h_, st));
         check_srbm(srbm_get_merit(h_, &merit, &merit_dd));
-        check_srbm(srbm_get_qp_cost(h_, &qpc));
         static const char* names[] = {"Solved", "Solved Inacc", "Max Iter", "P - Infeasible", "D - Infeasible", "P - Infeasible Inacc", "D - Infeasible Inacc", "Unsolved", "Other"};
         const int q = (int)GetSolveQuality();
         const int col_width = 15;
         using std::setw;
-        os << std::left << setw(col_width) << (solves_ - 1) << setw(col_width) << 0.0 << setw(col_width) << st[2] << setw(col_width) << st[3] << setw(col_width) << st[0]
+        // columns of mpc.cpp:979-988: i, solve_time_, equality violation, step norm, alpha, cost_result_, merit, merit dd, solve type, cost_ --
+        // cost_result_ and cost_ are both GetCostValue(prev_qp_sol) (mpc.cpp:809 and msrb.cpp:183-184), i.e. st[1] twice
+        os << std::left << setw(col_width) << (solves_ - 1) << setw(col_width) << last_solve_ms_ << setw(col_width) << st[2] << setw(col_width) << st[3] << setw(col_width) << st[0]
            << setw(col_width) << st[1] << setw(col_width) << merit << setw(col_width) << merit_dd << setw(col_width) << names[q < 0 || q > 8 ? 8 : q]
            << setw(col_width) << st[1] << std::endl;
     }
@@ -391,6 +634,12 @@ private:
     srbm_gait* gait_ = nullptr;
     bool used_log_file_ = false;
     int solves_ = 0;
+    double last_solve_ms_ = 0;
+    bool partials_as_data_ = true;
+    srbm_leg_kinematics legs_{};
+    bool has_legs_ = false;
+    mutable std::shared_ptr<SingleRigidBodyModel> kin_;      // built on first use (GetFullTargetState / GetModelCopy)
+    mutable QPData qp_data_;
 };
 using MPC = MPCSingleRigidBody;
 
@@ -404,8 +653,9 @@ public:
     QPPartialsDense& GetQPPartials() { return qp_partials_; }
     QPPartials& GetParameterPartials(int ee, int idx) {
         if (ee < 0 || ee >= num_ee_ || idx < 0) throw std::runtime_error("Parameter partial index out of range.");
-        if ((int)param_partials_.size() <= ee * 8 + idx) param_partials_.resize(ee * 8 + idx + 1);
-        return param_partials_[ee * 8 + idx];
+        if ((int)param_partials_.size() < num_ee_) param_partials_.resize(num_ee_);
+        if ((int)param_partials_[ee].size() <= idx) param_partials_[ee].resize(idx + 1);
+        return param_partials_[ee][idx];
     }
     void SetNumContactTimes(int ee, int num_times) { num_times_.at(ee) = num_times; }
     void UpdateSizes(int num_decision_vars, int num_constraints) { num_decision_vars_ = num_decision_vars; num_constraints_ = num_constraints; }
@@ -470,7 +720,7 @@ private:
     std::vector<time_v> contact_times_;
     std::vector<int> num_times_;
     QPPartialsDense qp_partials_;
-    std::vector<QPPartials> param_partials_;
+    std::vector<std::vector<QPPartials>> param_partials_;      // [ee][contact time]
     vector_t dHdth_;
     std::vector<double> step_, xk_;
     double pred_red_cost_ = 0;

@@ -60,6 +60,29 @@ int srbm_set_state_trajectory_warm_start(srbm_batch* h, const double* states);
 /* ClarabelInterface tolerances (mpc/qp/clarabel_interface.cpp:18-27,165-175) for the on-device IPM.
  * Defaults: the reference's own -- gap 1e-15, feasibility 1e-10 -- and 200 iterations (Clarabel's max_iter) */
 int srbm_set_solver_tolerances(srbm_batch* h, double tol_gap_abs, double tol_gap_rel, double tol_feas, int max_iter);
+/* Two settings of the on-device solver that have no counterpart in ClarabelInterface (mpc/qp/clarabel_interface.cpp:72-155 runs Clarabel to
+ * its 1e-15 gap).  tol_step > 0: a solve ALSO ends Solved as soon as the affine Newton step -- which measures the distance of the iterate to the
+ * minimiser of the QP -- is below tol_step * max(1, |u|_inf); the iterate then takes that step (what is left is <= 0.2 tol_step).  start_mu > 0:
+ * every solve is first attempted from Clarabel's starting point with the multipliers scaled to mean(s o lambda) = start_mu and repeated from the
+ * standard point unless the attempt ends through the step rule (device-resident K-step launches only -- srbm_rti_advance, srbm_closed_loop_advance --
+ * where a repeated attempt of one instance is averaged over its K steps; a one-step launch would wait for it every time).  Both 0: exactly the gap
+ * criterion of srbm_set_solver_tolerances.
+ * The bilevel step differentiates the KKT system of a solve and needs its duals at the reference's tolerance: srbm_gait_rti_advance runs that
+ * one solve of its protocol at the gap criterion by itself; a caller that drives the protocol (srbm_get_real_time_update, then
+ * srbm_gait_compute_gradient) switches the rule off for the batch -- the gradient of a solve that ended through the step rule is marked
+ * invalid (valid[b] = 0, as for a QP that is not Solved).
+ * Defaults: SRBM_DEFAULT_TOL_STEP, SRBM_DEFAULT_START_MU (1e-4 relative primal accuracy is the bar of the path). */
+#define SRBM_DEFAULT_TOL_STEP 1e-5
+#define SRBM_DEFAULT_START_MU 10.0
+int srbm_set_solver_step_rule(srbm_batch* h, double tol_step, double start_mu);
+int srbm_get_solver_step_rule(const srbm_batch* h, double* tol_step, double* start_mu);
+/* The library carries the kernels of the RTI path twice (same sources): set 0, one instance per CU (512 threads, the normal matrix of the solve in
+ * LDS) and set 1, two instances per CU (256 threads, <= 80 KB of LDS, the normal matrix in L2).  A batch with more instances than the GPU has
+ * CUs is created on set 1 -- the instances then fill each other's latency gaps -- every other batch on set 0; srbm_set_kernel_set overrides
+ * (-1 where set 1 does not exist: the LARGE build, horizons whose working set exceeds half a CU).  Same algorithm, same data; the results of
+ * the two sets agree to rounding (reductions over 4 instead of 8 waves), not bit for bit. */
+int srbm_set_kernel_set(srbm_batch* h, int which);
+int srbm_get_kernel_set(const srbm_batch* h);
 
 /* MPC::CreateInitialRun (mpc/mpc.cpp:78-90): 10 solves at t = 0.   state[batch][13], ee[batch][4][3] */
 int srbm_create_initial_run(srbm_batch* h, const double* state, const double* ee_start_locations);
@@ -117,12 +140,18 @@ int srbm_sizeof_trajectory(void);
 /* MPC::GetTrajectory (mpc/mpc.cpp:1023-1025) for instances [first, first + count): out[count] */
 int srbm_get_trajectory(srbm_batch* h, int first, int count, srbm_trajectory* out);
 /* MPC::SetWarmStartTrajectory (mpc/mpc.cpp:110-119) for instances [first, first + count): prev_traj_ = trajectory,
- * init_time_ = trajectory.GetTime(0).  The record is validated (knot counts, kinds, ordering); -1 on a malformed one. */
+ * init_time_ = trajectory.GetTime(0).  The record is validated (knot counts, kinds, ordering); -1 on a malformed one.  The solver's memory of the instance (the back-off
+ * of the lower-start attempts, srbm_set_solver_step_rule) is reset: two instances given the same trajectory solve the same next QP bit for bit. */
 int srbm_set_warm_start_trajectory(srbm_batch* h, int first, int count, const srbm_trajectory* trajs);
 /* Trajectory::GetForce / GetEndEffectorLocation / GetContacts at a time (mpc/trajectory.cpp:395-410, :70-80): pure host
  * arithmetic on a record (no GPU needed) -- what controllers/mpc_controller.cpp:171-186,352,415-509 evaluates at 1 kHz.
  * force[3], pos[3]; returns 0, or the error bits of the lookup (time outside the knot range: the reference throws). */
 int srbm_trajectory_eval(const srbm_trajectory* traj, int ee, double time, double* force3, double* pos3, int* in_contact);
+/* SingleRigidBodyModel::ConvertManifoldStateToTangentState / ConvertTangentStateToManifoldState (mpc/models/single_rigid_body_model.cpp:188-220;
+ * used by the caller at controllers/mpc_controller.cpp:60): [p, lin-mom, quat xyzw, ang-mom] (13) <-> [p, lin-mom, log3(quat), ang-mom] (12).
+ * Host arithmetic, the same functions the kernels use; the reference's ref_state argument is unused there (its quat_ref is the identity). */
+int srbm_convert_manifold_to_tangent(const double* state13, double* tangent12);
+int srbm_convert_tangent_to_manifold(const double* tangent12, double* state13);
 /* the same for the CURRENT trajectory of every instance on the device: time[batch] -> force[batch][4][3], pos[batch][4][3],
  * in_contact[batch][4] (any output may be NULL) */
 int srbm_eval_trajectory(srbm_batch* h, const double* time, double* force, double* pos, int* in_contact);
@@ -165,6 +194,11 @@ int srbm_gait_get_sensitivity(srbm_gait* g, double* d, int ld);
  * valid[batch] = 0 where the reference refuses (last QP not Solved, mpc.cpp:1048) -- may be NULL */
 int srbm_gait_compute_gradient(srbm_gait* g);
 int srbm_gait_get_gradient(srbm_gait* g, double* dHdth, int* valid);
+/* MPCSingleRigidBody::ComputeParamPartialsClarabel (mpc/mpc_single_rigid_body.cpp:642-792; read as matrices at test/mpc_test.cpp:181-184 and
+ * mpc/gait_optimizer.cpp:92-179): partials of the QP of the last solve of instance `inst` w.r.t. contact time `idx` of foot `ee`, on the instance's
+ * current trajectory, dense, in the layout of mpc::QPPartials (mpc/include/qp/qp_partials.h:15-35): dA [n_eq][n], dG [n_ineq][n], db [n_eq],
+ * dh [n_ineq] (zero as coded); sizes from srbm_get_sizes.  Debug path like srbm_export_qp (the gradient kernel contracts the same entries on the fly). */
+int srbm_gait_get_param_partials(srbm_batch* h, int inst, int ee, int idx, double* dA, double* dG, double* db, double* dh);
 /* GaitOptimizer::OptimizeContactTimes (gait_optimizer.cpp:185-364): the LP  min dHdth' s  over the polytope of
  * gait_optimizer.cpp:410-534 at time[batch]; the step stays on the device for the line search.
  * lp_status[batch]: 0 solved, 1 iteration limit, 2 numerical failure (the reference throws "Bad gait optimization
@@ -243,6 +277,8 @@ int srbm_get_status(srbm_batch* h, int* status, int* err);
  * step): acc[batch][4] = {all error bits raised, solves, solves not in {Solved, SolvedInacc}, of those MaxIter} */
 int srbm_get_status_accumulated(srbm_batch* h, int* acc);
 int srbm_clear_status_accumulators(srbm_batch* h);
+/* counters over the same span: c[4] = {solves, solves ended by the step rule, lower-start attempts, attempts repeated from the standard start} */
+int srbm_get_solver_counters(srbm_batch* h, long long* c4);
 /* stats[batch][8] = alpha, cost (GetCost), L1 dynamics defect, step norm, qp iterations, res_primal, res_dual, gap_rel */
 int srbm_get_stats(srbm_batch* h, double* stats);
 /* objective of the QP at its raw minimiser, cost[batch] (the "QP Cost" column of MPC::PrintStatLineToFile, mpc/mpc.cpp:974-989) */
@@ -275,6 +311,8 @@ int srbm_pack_results(srbm_batch* h, double* out, int ld);
  * of executed IPM iterations / algorithmic flops (SURVEY.md section 8d formula) summed over the batch */
 int srbm_enable_kernel_timing(srbm_batch* h, int max_launches);
 int srbm_get_kernel_timing(srbm_batch* h, double* total_ms, int* launches);
+/* ... and launch by launch: ms_each[min(launches, max_launches)] in launch order (bench.py prices the MEDIAN region with its own launch) */
+int srbm_get_kernel_timings(srbm_batch* h, double* ms_each, int max_launches, int* launches);
 int srbm_get_work_counters(srbm_batch* h, double* total_ipm_iterations, double* total_algorithmic_flops);
 /* matrix-core instructions (v_mfma_f64_16x16x4_f64, 2048 flop each, counted per wave) EXECUTED by the condensing and IPM
  * phases, summed over the batch: the executed-flop side of the roofline (the algorithmic figure counts a dense SYRK that the

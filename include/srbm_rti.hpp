@@ -67,6 +67,7 @@ public:
     void SetLinearFinalCost(const vector_t& w) { need(w, 12); check(srbm_set_linear_final_cost(h_, w.data())); }
     // ClarabelInterface::ConfigureForInitialRun / ConfigureForSolve tolerances (clarabel_interface.cpp:165-175)
     void SetSolverTolerances(double gap_abs, double gap_rel, double feas, int max_iter) { check(srbm_set_solver_tolerances(h_, gap_abs, gap_rel, feas, max_iter)); }
+    void SetSolverStepRule(double tol_step, double start_mu) { check(srbm_set_solver_step_rule(h_, tol_step, start_mu)); }
     // MPC::SetStateTrajectoryWarmStart (mpc.cpp:700-706): states [batch][13]
     void SetStateTrajectoryWarmStart(const vector_t& states) { need(states, 13 * batch_); check(srbm_set_state_trajectory_warm_start(h_, states.data())); }
     // MPC::CreateInitialRun (mpc.cpp:78-90): state [batch][13], ee_start_locations [batch][4][3]

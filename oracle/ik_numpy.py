@@ -159,9 +159,12 @@ def inverse_kinematics(legs, state13, ee_des, q_guess):
     q = np.array(q_guess, float).copy()
     q[:3] = state13[:3]; q[3:7] = state13[6:10]
     R_des, p_des = quat_to_R(state13[6:10]), np.asarray(state13[:3], float)
+    # `bool success = false;` is declared ONCE, before the foot loop (single_rigid_body_model.cpp:356), and `if (!success) throw` sits inside it
+    # (:414-416): once one foot has converged, a later foot that stops at IT_MAX no longer throws.  As coded: failure is reported iff no foot
+    # up to and including the current one has converged, i.e. iff foot 0 fails (the per-foot iteration counts still show a foot at IT_MAX).
     iters, ok = [], True
+    success = False
     for ee in range(4):
-        success = False
         it = 0
         for it in range(IT_MAX):
             q[3:7] = first_order_normalize(q[3:7])

@@ -18,6 +18,7 @@ if len(sys.argv) > 1 and sys.argv[1] == '--child':
     states, ees = np.array(states), np.array(ees).reshape(B, 12)
     g = host.BatchMPC(cfg, B); g.set_state_trajectory_warm_start(states)
     if 'AB_TOL' in os.environ: g.set_solver_tolerances(float(os.environ['AB_TOL']), float(os.environ['AB_TOL']), 1e-10, 200)
+    if 'AB_STEP' in os.environ: g.set_solver_step_rule(float(os.environ['AB_STEP']), float(os.environ.get('AB_MU', 0)))
     for _ in range(10): g.create_initial_run(states, ees)
     g.rti_advance(0, 5); g.synchronize()
     if os.environ.get('AB_WINDOWS'):      # five 20-step launches timed one by one (the bench's timed regions)
@@ -29,7 +30,8 @@ if len(sys.argv) > 1 and sys.argv[1] == '--child':
               int(acc[:, 2].sum()), int(np.bitwise_or.reduce(acc[:, 0]))))
     t0 = time.perf_counter(); g.rti_advance(5, 40); g.synchronize(); t1 = time.perf_counter()
     st = g.status()[0]; x = g.qp_solution()
-    print('%-40s tol %s  %.3f ms/step  iters %.2f  statuses %s  checksum %.17g' % (os.path.basename(os.environ['SRBM_RTI_LIB']), os.environ.get('AB_TOL', 'default'), (t1 - t0) / 40 * 1e3,
+    print('%-30s tol %s step %s mu %s counters %s  %.3f ms/step  iters %.2f  statuses %s  checksum %.17g' % (os.path.basename(os.environ['SRBM_RTI_LIB']), os.environ.get('AB_TOL', 'default'),
+          os.environ.get('AB_STEP', 'default'), os.environ.get('AB_MU', 'default'), g.solver_counters(), (t1 - t0) / 40 * 1e3,
           g.stats()[:, 4].mean(), dict(zip(*np.unique(st, return_counts=True))), float(np.nansum(x * np.cos(np.arange(x.size).reshape(x.shape))))))
 else:
     for lib in sys.argv[1:]:

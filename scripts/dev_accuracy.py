@@ -12,7 +12,9 @@ from bench import config_b_instance
 cfg = load_config()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-tols = [float(v) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else [1e-13, 1e-14, 1e-15]
+# variants: gap tolerance[:tol_step[:start_mu]] (srbm_set_solver_tolerances / srbm_set_solver_step_rule), comma separated
+tols = [tuple(float(x) for x in v.split(':')) for v in sys.argv[3].split(',')] if len(sys.argv) > 3 else [(1e-13,), (1e-14,), (1e-15,)]
+tols = [t + (0.0,) * (3 - len(t)) for t in tols]
 states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
 states, ees = np.array(states), np.array(ees)
 pool = ThreadPoolExecutor(16)
@@ -22,7 +24,8 @@ for b in range(B):
 list(pool.map(lambda b: os_[b].initial_run(states[b], ees[b]), range(B)))
 gs = []
 for tol in tols:
-    g = host.BatchMPC(cfg, B); g.set_state_trajectory_warm_start(states); g.set_solver_tolerances(tol, tol, 1e-10, 200)
+    g = host.BatchMPC(cfg, B); g.set_state_trajectory_warm_start(states); g.set_solver_tolerances(tol[0], tol[0], 1e-10, 200)
+    g.set_solver_step_rule(tol[1], tol[2])
     g.create_initial_run(states, ees.reshape(B, 12))
     gs.append(g)
 for i in range(STEPS):
@@ -37,6 +40,7 @@ for i in range(STEPS):
         g.get_real_time_update(st_in, t, ee_in)
         xr = g.raw_qp_minimiser(); st, err = g.status(); stats = g.stats()
         e = np.array([np.abs(xr[b, :len(xo[b])] - xo[b]).max() / max(1.0, np.abs(xo[b]).max()) if sos[b] <= 1 and st[b] <= 1 else 0.0 for b in range(B)])
-        print('step %d tol %.0e: max %.2e  p99 %.2e  median %.2e  >1e-4: %d  >5e-5: %d  >1e-5: %d   mean iters %.1f  statuses %s  worst inst %d (iters %d, oracle st %d, gap %.1e)' %
-              (i, tol, e.max(), np.percentile(e, 99), np.median(e), (e > 1e-4).sum(), (e > 5e-5).sum(), (e > 1e-5).sum(), stats[:, 4].mean(),
+        cnt = g.solver_counters()
+        print('step %d tol %s (step rule %d / %d, low tried %d failed %d): max %.2e  p99 %.2e  median %.2e  >1e-4: %d  >5e-5: %d  >1e-5: %d   mean iters %.1f  statuses %s  worst inst %d (iters %d, oracle st %d, gap %.1e)' %
+              (i, ':'.join('%g' % v for v in tol), cnt['step_rule'], cnt['solves'], cnt['low_tried'], cnt['low_failed'], e.max(), np.percentile(e, 99), np.median(e), (e > 1e-4).sum(), (e > 5e-5).sum(), (e > 1e-5).sum(), stats[:, 4].mean(),
                dict(zip(*np.unique(st, return_counts=True))), e.argmax(), stats[e.argmax(), 4], sos[e.argmax()], stats[e.argmax(), 7]))

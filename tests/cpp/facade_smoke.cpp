@@ -26,6 +26,7 @@ int main() {
     for (int i = 0; i < 12; i++) w[i] = -kQdiag[i] * des[i];
     mpc.SetLinearFinalCost(w);
     mpc.SetSolverTolerances(1e-15, 1e-15, 1e-10, 200);
+    mpc.SetSolverStepRule(0.0, 0.0);      // the gradient below differentiates the last solve: gap criterion (include/srbm_rti.h)
     vector_t state(13 * B), ee(12 * B), t(B, 0.0);
     const double ee0[12] = {0.2, 0.2, 0, 0.2, -0.2, 0, -0.2, 0.2, 0, -0.2, -0.2, 0};
     for (int b = 0; b < B; b++) { for (int i = 0; i < 13; i++) state[13 * b + i] = kInit[i]; for (int i = 0; i < 12; i++) ee[12 * b + i] = ee0[i]; }

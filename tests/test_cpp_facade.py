@@ -68,6 +68,7 @@ def test_cpp_host_side_equals_ctypes_path(tmp_path):
     g = host.BatchMPC(cfg, 2)
     g.set_state_trajectory_warm_start(s0)
     g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
+    g.set_solver_step_rule(0.0, 0.0)
     g.create_initial_run(s0, ee0)
     g.rti_advance(0, 4); g.synchronize()
     gait = host.BatchGaitOptimizer(g)
@@ -190,6 +191,7 @@ def test_mpc_facade_runs_the_controller_protocol_like_the_ctypes_path(tmp_path):
     ee0 = np.array([[0.2, 0.2, 0], [0.2, -0.2, 0], [-0.2, 0.2, 0], [-0.2, -0.2, 0]], float)
     g = host.BatchMPC(cfg, 1)
     g.set_state_trajectory_warm_start(s0)
+    g.set_solver_step_rule(0.0, 0.0)                # as mpc::MPCSingleRigidBody of the facade does (gap criterion for every solve)
     g.add_force_cost(cfg['force_cost'])
     g.create_initial_run(s0, ee0)
     gait = host.BatchGaitOptimizer(g)
@@ -278,6 +280,7 @@ def test_row_f3_facade_runs_the_control_tick_like_the_ctypes_path(tmp_path):
     q0 = np.array(gold['source']['init_config'], float)
     g = host.BatchMPC(cfg, 1)
     g.set_state_trajectory_warm_start(s0)
+    g.set_solver_step_rule(0.0, 0.0)                # as mpc::MPCSingleRigidBody of the facade does (gap criterion for every solve)
     g.add_force_cost(cfg['force_cost'])
     ee0 = g.forward_kinematics(q0)[0]
     ee0[:, 2] = 0
@@ -306,3 +309,96 @@ def test_row_f3_facade_runs_the_control_tick_like_the_ctypes_path(tmp_path):
     assert np.abs(np.array(vals['q_des']) - q_des[0]).max() < 1e-9, np.abs(np.array(vals['q_des']) - q_des[0]).max()
     assert np.abs(np.array(vals['v_des']) - v_des[0]).max() < 1e-6 * max(1.0, np.abs(v_des).max())
     assert np.abs(np.array(vals['control']) - ctl[0]).max() < 1e-6 * max(1.0, np.abs(ctl).max()), np.abs(np.array(vals['control']) - ctl[0]).max()
+
+
+# ---------------- the callers outside the controller: gait_opt_playground.cpp, mpc_test.cpp "Model Partials", the model's maps ----------------
+def build_playground(tmpdir):
+    cfg = host.load_config('a1_configuration')
+    host.build()
+    write_cfg_inc(cfg, os.path.join(tmpdir, 'cfg.inc'))
+    exe = os.path.join(tmpdir, 'gait_playground_callsites')
+    libdir = os.path.dirname(host.LIB_PATH)
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), '-I', tmpdir,
+                           os.path.join(CPP, 'gait_playground_callsites.cpp'), '-o', exe, '-L', libdir, '-lsrbm_rti', '-Wl,-rpath,' + libdir])
+    return cfg, exe
+
+
+def test_playground_and_partials_call_sites_compile_against_the_mpc_facade(tmp_path):
+    """test/gait_opt_playground.cpp:26-58,66-147 (GetFullTargetState, GetQPData, GetModifiedCost), test/mpc_test.cpp:114-270 (QPPartials read as
+    matrices, finite differences of GetQPData().sparse_constraint_), controllers/mpc_controller.cpp:60,258 on MPC::GetModelCopy(): transcribed in
+    tests/cpp/gait_playground_callsites.cpp, warning-free against include/mpc_facade/mpc.h."""
+    cfg, exe = build_playground(str(tmp_path))
+    assert os.path.exists(exe)
+
+
+@pytest.mark.gpu
+def test_playground_protocol_and_the_reference_partials_test_through_the_facade(tmp_path):
+    """Runs the transcription: (1) the reference's own "Model Partials" test passes on the device through mpc::QPPartials / mpc::QPData
+    (every dynamics / force-box / friction-cone entry within 1e-4 of the finite difference, all contact times with idx >= 1);
+    (2) the QP sizes are stable across every solve of the playground loop (the asserts of gait_opt_playground.cpp:129-130);
+    (3) GetFullTargetState, the costs and the optimised schedule equal the same call sequence through the Python binding."""
+    cfg, exe = build_playground(str(tmp_path))
+    urdf = os.path.join(str(tmp_path), 'from_constants.urdf')
+    gold = write_urdf_from_golden(urdf)
+    ITER = 6
+    vals = parse_dump(subprocess.check_output([exe, urdf, str(ITER)], text=True))
+    # model maps (mpc_controller.cpp:60, :258)
+    tgt = np.array(cfg['srb_target'], float)
+    assert np.abs(np.array(vals['des_alg']) - host.manifold_to_tangent(tgt)).max() < 1e-15
+    assert np.abs(np.array(vals['des_back']) - tgt).max() < 1e-14
+    assert np.abs(np.array(vals['Ir_w']) - np.array(gold['Ir']).reshape(3, 3) @ np.array([0.3, -0.2, 0.1])).max() < 1e-12
+    # (1) test/mpc_test.cpp:114-270
+    assert vals['partials_checked'][0] >= 12 and vals['partials_worst_fd'][0] < 1e-4, vals['partials_worst_fd']
+    # (2)
+    assert vals['qp_same_size'] == [1.0] * ITER and len(set(vals['qp_n'])) == 1 and vals['qp_n'][0] == 372.0
+    # (3) the same protocol through ctypes
+    s0 = np.array(cfg['srb_init'], float)
+    ee0 = np.array([[0.2, 0.2, 0], [0.2, -0.2, 0], [-0.2, 0.2, 0], [-0.2, -0.2, 0]], float)
+    g = host.BatchMPC(cfg, 1)
+    g.set_state_trajectory_warm_start(s0)
+    g.set_solver_step_rule(0.0, 0.0)
+    g.add_force_cost(cfg['force_cost'])
+    g.create_initial_run(s0, ee0)
+    gait = host.BatchGaitOptimizer(g)
+    traj = g.get_trajectory()[0]
+    state = np.array(gold['source']['init_config'], float)
+    sched_before = np.concatenate(traj.get_contact_times())
+    ik, costs, gait_steps = [], [], 0
+    for i in range(ITER):
+        t = 0.0                                   # fixed_pos = true (gait_opt_playground.cpp:85-87,364-365)
+        cur = g.get_trajectory()[0]
+        ee_now = np.array([cur.get_end_effector_location(e, t) for e in range(4)])
+        q, _, st = g.inverse_kinematics(cur.get_states()[cur.get_node(t)], ee_now.reshape(1, 12), state)
+        assert st[0] == 0
+        state = q[0]; ik.append(state)
+        ee = np.array([traj.get_end_effector_location(e, t) for e in range(4)]).reshape(1, 12)
+        if i % 2 == 0 and g.status()[0][0] == 0:
+            gait.compute_sensitivity(); gait.compute_gradient()
+            _, valid = gait.gradient()
+            assert valid[0] == 1
+            gait.optimize_contact_times(t)
+            xk, counts = gait.contact_times(); step = gait.step()
+            new = xk[0] + step[0]
+            times = np.zeros((1, 4, 8)); off = 0
+            ct = g.get_trajectory()[0].get_contact_times()
+            for e in range(4):
+                for k in range(counts[0, e]):
+                    v = new[off + k]
+                    if k > 0:
+                        d = times[0, e, k - 1] - v
+                        if 0 < d <= 1e-3: v = times[0, e, k - 1]
+                    times[0, e, k] = v
+                off += counts[0, e]
+            g.update_contact_times(times)
+            gait_steps += 1
+        g.get_real_time_update(traj.get_states()[0], t, ee)
+        traj = g.get_trajectory()[0]
+        costs.append(g.cost()[0])
+    assert vals['gait_steps'][0] == gait_steps and gait_steps == 3
+    assert np.array_equal(np.array(vals['modified_cost']), np.array(costs))
+    assert np.array_equal(np.array(vals['ik_state']), np.concatenate(ik))
+    assert np.array_equal(np.array(vals['sched_before']), sched_before)
+    sched_after = np.concatenate(traj.get_contact_times())
+    assert np.array_equal(np.array(vals['sched_after']), sched_after) and not np.array_equal(sched_after, sched_before)
+    assert len(vals['target_config']) == 7 and np.array_equal(np.array(vals['target_config']), traj.get_states()[1][6:])
+    assert len(vals['force_target']) in (6, 12)

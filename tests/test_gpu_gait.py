@@ -23,6 +23,7 @@ def run_pair(cfgname, nsteps, batch=2, tol=1e-15):
     g = host.BatchMPC(cfg, batch)
     g.set_state_trajectory_warm_start(s0)
     g.set_solver_tolerances(tol, tol, 1e-10, 200)
+    g.set_solver_step_rule(0.0, 0.0)        # the caller drives the protocol here: the solves it differentiates run to the gap criterion (include/srbm_rti.h)
     o = OracleMPC(cfg)
     o.set_warmstart(s0)
     g.create_initial_run(s0, EE0); o.initial_run(s0, EE0)
@@ -251,6 +252,7 @@ def test_controller_loop_with_gait_step(cfgname, runs, knot_tol, resync):
     g = host.BatchMPC(cfg, 2)
     g.set_state_trajectory_warm_start(s0)
     g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
+    g.set_solver_step_rule(0.0, 0.0)
     o = OracleMPC(cfg)
     o.set_warmstart(s0)
     g.create_initial_run(s0, EE0); o.initial_run(s0, EE0)
@@ -319,6 +321,7 @@ def test_gait_step_of_a_seeded_batch_of_32_against_the_oracle():
     g = host.BatchMPC(cfg, B)
     g.set_state_trajectory_warm_start(states)
     g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
+    g.set_solver_step_rule(0.0, 0.0)
     os_ = []
     for b in range(B):
         o = OracleMPC(cfg); o.set_warmstart(states[b]); os_.append(o)

@@ -52,10 +52,17 @@ def test_forward_and_inverse_kinematics_match_the_oracle():
         assert np.abs(qs[b] - qo).max() < 1e-8, (b, np.abs(qs[b] - qo).max())
     back = g.forward_kinematics(qs)
     assert np.abs(back - des).max() < 2e-5            # FK o IK = identity to the solver's tolerance (5e-6 per foot, feet in turn)
-    # an unreachable target is reported, never silently accepted (the reference throws "IK did not converge.")
-    far = des.copy(); far[0, 2] += [1.0, 0.0, -1.0]
+    # an unreachable target: the reference throws "IK did not converge." only while NO foot has converged yet (its `success` flag is declared
+    # before the foot loop, single_rigid_body_model.cpp:356,414): foot 0 out of reach -> status 1; foot 2 out of reach after feet 0 and 1
+    # converged -> status 0 as coded, and the iteration count of that foot (IT_MAX) is what tells
+    far = des.copy(); far[0, 0] += [1.0, 0.0, -1.0]; far[1, 2] += [1.0, 0.0, -1.0]
     _, it2, st2 = g.inverse_kinematics(state, far.reshape(B, 12), q)
-    assert st2[0] == 1 and it2[0, 2] == 1000 and np.all(st2[1:] == 0)
+    assert st2[0] == 1 and it2[0, 0] == 1000
+    assert st2[1] == 0 and it2[1, 2] == 1000 and np.all(it2[1, :2] < 1000)
+    assert np.all(st2[2:] == 0)
+    for b in (0, 1):
+        _, ito, ok = ik.inverse_kinematics(legs, state[b], far[b], q[b])
+        assert ok == (st2[b] == 0) and list(it2[b]) == ito
 
 
 def test_targets_from_trajectory_match_the_oracle():

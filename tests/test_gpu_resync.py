@@ -33,11 +33,13 @@ def cls(v):
     return 'solved' if v <= 1 else ('maxiter' if v == 2 else ('infeasible' if v in (3, 5) else 'other'))
 
 
-def make_batch(cfg, states, ees):
+def make_batch(cfg, states, ees, step_rule=True):
     B = len(states)
     g = host.BatchMPC(cfg, B)
     g.set_state_trajectory_warm_start(states)
     g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
+    if not step_rule:
+        g.set_solver_step_rule(0.0, 0.0)        # exactly the reference's criterion (gap 1e-15): include/srbm_rti.h
     oracles = []
     for b in range(B):
         o = OracleMPC(cfg)
@@ -46,13 +48,13 @@ def make_batch(cfg, states, ees):
     return g, oracles
 
 
-def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None):
+def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None, step_rule=True, min_alive=None):
     """cold start on both sides, then `steps` open-loop RTI steps (test/gait_opt_playground.cpp:113-126) with the device
     re-synchronised to the oracle before every step; returns per-step statistics.  Asserts entry-wise parity."""
     B = len(states)
     N = cfg['num_nodes']
     dt = cfg['integrator_dt']
-    g, oracles = make_batch(cfg, states, ees)
+    g, oracles = make_batch(cfg, states, ees, step_rule)
     pool = pool or ThreadPoolExecutor(16)
     list(pool.map(lambda b: oracles[b].initial_run(states[b], ees[b].reshape(4, 3)), range(B)))
     g.create_initial_run(states, ees.reshape(B, 12))
@@ -62,7 +64,7 @@ def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None):
     for b in range(B):
         so = oracles[b].stats()['status']
         assert cls(st0[b]) == cls(so) or {cls(st0[b]), cls(so)} <= {'solved', 'maxiter'}, (b, st0[b], so)
-    seen_sizes, seen_td, worst = set(), 0, dict(A=0.0, x=0.0, z=0.0, z_all=0.0, states=0.0, x_cert_oracle=0.0, x_cert_gpu=0.0)
+    seen_sizes, seen_td, worst = set(), 0, dict(A=0.0, x=0.0, z=0.0, z_all=0.0, states=0.0, x_cert_oracle=0.0, x_cert_gpu=0.0, dual_obj=0.0)
     n_cert = 0
     n_unique = 0
     exact_status = 0
@@ -161,7 +163,13 @@ def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None):
                 ineq = slice(nx, nx + osz['n_ineq'])
                 assert zg[ineq].min() > -1e-7 * zs and sg[ineq].min() > -1e-9, (i, b)
                 assert np.abs(zg[ineq] * sg[ineq]).max() < 1e-6 * zs, (i, b)
-                assert abs(bo @ zg - bo @ zo) <= 1e-6 * max(1.0, abs(bo @ zo)), (i, b, bo @ zg, bo @ zo)
+                # dual objective b'z: a sum of terms of both signs (|b'z| ~ 1e2 out of terms b_i z_i of 1e4 and more).  At the reference's gap
+                # criterion (step_rule=False) both sides agree to 1e-6 OF THE SUM, which is a 1e-8 statement on the multipliers.  The step rule
+                # (the default of the library) bounds the primal distance to the minimiser (5e-6 relative) and leaves the
+                # multipliers accurate to that order: the sum then agrees to 1e-6 of the magnitude of its TERMS -- asserted as such
+                dscale = abs(bo @ zo) if not step_rule else np.abs(bo * zo).sum()
+                out['dual_obj'] = abs(bo @ zg - bo @ zo) / max(1.0, abs(bo @ zo))
+                assert abs(bo @ zg - bo @ zo) <= 1e-6 * max(1.0, dscale), (i, b, bo @ zg, bo @ zo, dscale)
                 active = np.ones(m, bool)
                 active[ineq] = so_[ineq] < 1e-7
                 active &= np.abs(Ao).sum(axis=1) > 0      # rows without coefficients constrain nothing
@@ -194,7 +202,7 @@ def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None):
         for b in (0, B // 2, B - 1):
             if alive[b]:
                 assert np.array_equal(g.knots(b)['box'], np.array(oracles[b].stats()['box'])), (i, b)
-    assert alive.sum() >= 0.97 * B, alive.sum()
+    assert alive.sum() >= (0.97 * B if min_alive is None else min_alive), alive.sum()
     return dict(alive=int(alive.sum()), sizes=seen_sizes, td_steps=seen_td, worst=worst, exact_status=exact_status, total=total, z_unique=n_unique, certified=n_cert)
 
 
@@ -203,7 +211,7 @@ def test_config_b_all_256_instances_entrywise_over_20_steps():
     B = 256
     states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
     states, ees = np.array(states), np.array(ees)
-    r = resync_protocol(cfg, states, ees, steps=20)
+    r = resync_protocol(cfg, states, ees, steps=20, min_alive=255)       # (one instance leaves at step 2: the ORACLE reports MaxIterations there)
     nx = 21 * 12
     assert {nx + 120, nx + 148} <= r['sizes'], r['sizes']         # both window sizes were compared
     assert r['td_steps'] > 0                                      # ... and steps with touch-down position rows
@@ -211,6 +219,18 @@ def test_config_b_all_256_instances_entrywise_over_20_steps():
     print('resync parity, 256 x 20: alive', r['alive'], 'worst', r['worst'], 'exact status matches %d / %d' % (r['exact_status'], r['total']),
           'duals compared entry-wise (unique multipliers) in %d solves' % r['z_unique'], 'certified minimisers: %d' % r['certified'])
     assert r['certified'] >= 40
+
+
+def test_config_b_at_the_reference_criterion_entrywise():
+    """The same protocol with the step rule and the lower start switched off (srbm_set_solver_step_rule(0, 0)): every solve runs to Clarabel's
+    gap criterion as in round 2, and the dual objectives agree to 1e-6 of their value -- 64 instances x 10 steps"""
+    cfg = load_config()
+    B = 64
+    states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees)
+    r = resync_protocol(cfg, states, ees, steps=10, step_rule=False)
+    assert r['worst']['A'] <= 1e-12 and r['worst']['x'] < REL_TOL and r['worst']['z'] < REL_TOL and r['worst']['dual_obj'] <= 1e-6
+    print('resync parity at the reference criterion, 64 x 10: worst', r['worst'])
 
 
 def test_config_c_values_at_n20_entrywise():
@@ -259,6 +279,8 @@ def test_trajectory_roundtrip_clone_and_evaluation():
     d = host.BatchMPC(cfg, B)
     d.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
     d.set_warm_start_trajectory(g.get_trajectory())
+    g.set_warm_start_trajectory(g.get_trajectory())     # (installing a trajectory also resets the solver's per-instance memory: the back-off of the
+                                                        #  lower-start attempts -- g has five solves of history, d has none)
     tr = g.trajectory_states()
     t5 = 5 * cfg['integrator_dt']
     f, p, cont = g.eval_trajectory(t5)
