@@ -533,10 +533,11 @@ def main():
                                     'distribution on the initial momentum, 10 cold-start solves then open-loop RTI steps' % B) if args.workload == 'D' else
                                    ('Config E (SRBM stand-in for the dead centroidal MPC, no reference parity beyond the SRBM restatement): %d instances per GPU, '
                                     'N=40, dt=0.05, a1_configuration.yaml values, LARGE-capacity build (normal matrix in L2)' % B),
-                       'batch_per_gpu': B, 'global_batch': n_inst, 'num_nodes': cfg['num_nodes'], 'parallelism': 'instances sharded x%d' % world,
+                       'batch_per_gpu': B, 'global_batch': n_inst, 'num_nodes': cfg['num_nodes'], 'kernel_set': mpc.kernel_set(), 'parallelism': 'instances sharded x%d' % world,
                        'records_gathered': int(allrec.shape[0]), 'record_doubles': LD,
                        'all_solved': bool(q[2] == 0 and q[0] == 0), 'statuses_last_step': {int(k): int(v) for k, v in zip(*np.unique(status_all, return_counts=True))},
                        'timed_solves': int(q[1]), 'not_solved_in_timed_solves': int(q[2]), 'max_iter_in_timed_solves': int(q[3]),
+                       'instances_with_a_solve_not_solved_rank0': [int(lo + b) for b in np.nonzero(acc_main[:, 2])[0][:64]],
                        'err_bits_all_timed_steps': int(q[0]) | int(np.bitwise_or.reduce(err_all)),
                        'mean_ipm_iterations': (it1 - it0) / max(1, (hi - lo) * args.steps * args.repeats),
                        'solver': {'tol_gap': 1e-15, 'tol_feas': 1e-10, 'tol_step': mpc.solver_step_rule()[0], 'start_mu': mpc.solver_step_rule()[1],

@@ -1643,6 +1643,17 @@ int srbm_get_targets_from_traj(srbm_batch* h, const double* time, double* q_des,
     return 0;
 }
 
+// the same on device pointers: one launch on the batch's stream, no copy, no synchronisation (a control tick of the whole batch stays in HBM)
+int srbm_get_targets_from_traj_dev(srbm_batch* h, const double* time_dev, double* q_des_dev, double* v_des_dev, double* force_des_dev, int* status_dev) {
+    if (!h || !time_dev || !q_des_dev || !v_des_dev || !force_des_dev || !status_dev) return fail("bad arguments");
+    if (need_legs(h)) return -1;
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    hipLaunchKernelGGL(srbm_k_targets_from_traj, dim3(h->batch), dim3(SRBM_IK_THREADS), 0, h->stream, h->dp, h->insts, time_dev, q_des_dev, v_des_dev, force_des_dev, status_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int srbm_set_wbc_model(srbm_batch* h, const srbm_wbc_model* m) {
     if (!h || !m) return fail("bad arguments");
     HIPCHK(hipSetDevice(h->device));
@@ -1702,6 +1713,19 @@ int srbm_qp_control(srbm_batch* h, const double* q, const double* v, const int* 
     if (qp_sol) memcpy(qp_sol, ho + 36 * B, sizeof(double) * WBC_NMAX * B);
     if (status) memcpy(status, ho + n_out_d, sizeof(int) * B);
     if (qp_dump) memcpy(qp_dump, ho + n_out_d + n_st_d, sizeof(double) * DUMP * B);
+    return 0;
+}
+
+int srbm_qp_control_dev(srbm_batch* h, const double* q_dev, const double* v_dev, const int* contact_dev, const double* q_des_dev, const double* v_des_dev,
+                        const double* force_des_dev, double* control_dev, double* qp_sol_dev, int* status_dev) {
+    if (!h || !q_dev || !v_dev || !contact_dev || !q_des_dev || !v_des_dev || !force_des_dev || !control_dev || !qp_sol_dev || !status_dev) return fail("bad arguments");
+    if (need_legs(h)) return -1;
+    if (!h->d_wbc) return fail("the whole-body model has not been set (srbm_set_wbc_model)");
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    hipLaunchKernelGGL(srbm_k_qp_control, dim3(h->batch), dim3(WBC_THREADS), 0, h->stream, h->dp, h->d_wbc, q_dev, v_dev, contact_dev, q_des_dev, v_des_dev,
+                       force_des_dev, control_dev, qp_sol_dev, status_dev, static_cast<double*>(nullptr));
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

@@ -419,6 +419,13 @@ class BatchMPC:
         self._chk(self.L.srbm_inverse_kinematics(self.h, _d(s), _d(e), _d(g), _d(q), _i(it), _i(st)))
         return q, it, st
 
+    def get_targets_from_traj_dev(self, time_ptr, q_des_ptr, v_des_ptr, force_des_ptr, status_ptr):
+        """the same on device pointers (ints, e.g. torch tensors' data_ptr()): one launch on the batch's stream, no copy, no synchronisation"""
+        self._chk(self.L.srbm_get_targets_from_traj_dev(self.h, C.c_void_p(time_ptr), C.c_void_p(q_des_ptr), C.c_void_p(v_des_ptr), C.c_void_p(force_des_ptr), C.c_void_p(status_ptr)))
+
+    def qp_control_dev(self, q, v, contact, q_des, v_des, force_des, control, qp_sol, status):
+        self._chk(self.L.srbm_qp_control_dev(self.h, *[C.c_void_p(p) for p in (q, v, contact, q_des, v_des, force_des, control, qp_sol, status)]))
+
     def get_targets_from_traj(self, time, q_des):
         """MPCController::GetTargetsFromTraj on the current trajectories -> (q_des, v_des [batch][18], force_des [batch][4][3], status)"""
         t = np.ascontiguousarray(np.broadcast_to(np.asarray(time, dtype=np.float64), (self.batch,)))

@@ -63,7 +63,8 @@ int srbm_set_solver_tolerances(srbm_batch* h, double tol_gap_abs, double tol_gap
 /* Two settings of the on-device solver that have no counterpart in ClarabelInterface (mpc/qp/clarabel_interface.cpp:72-155 runs Clarabel to
  * its 1e-15 gap).  tol_step > 0: a solve ALSO ends Solved as soon as the affine Newton step -- which measures the distance of the iterate to the
  * minimiser of the QP -- is below tol_step * max(1, |u|_inf); the iterate then takes that step (what is left is <= 0.2 tol_step).  start_mu > 0:
- * every solve is first attempted from Clarabel's starting point with the multipliers scaled to mean(s o lambda) = start_mu and repeated from the
+ * every solve is first attempted from the linearisation point (the shifted solution of the previous RTI step) with slacks h - G u and perfectly
+ * centred multipliers lambda = start_mu / s -- five to six decades further down the central path than Clarabel's starting point -- and repeated from the
  * standard point unless the attempt ends through the step rule (device-resident K-step launches only -- srbm_rti_advance, srbm_closed_loop_advance --
  * where a repeated attempt of one instance is averaged over its K steps; a one-step launch would wait for it every time).  Both 0: exactly the gap
  * criterion of srbm_set_solver_tolerances.
@@ -73,7 +74,7 @@ int srbm_set_solver_tolerances(srbm_batch* h, double tol_gap_abs, double tol_gap
  * invalid (valid[b] = 0, as for a QP that is not Solved).
  * Defaults: SRBM_DEFAULT_TOL_STEP, SRBM_DEFAULT_START_MU (1e-4 relative primal accuracy is the bar of the path). */
 #define SRBM_DEFAULT_TOL_STEP 1e-5
-#define SRBM_DEFAULT_START_MU 10.0
+#define SRBM_DEFAULT_START_MU 0.1
 int srbm_set_solver_step_rule(srbm_batch* h, double tol_step, double start_mu);
 int srbm_get_solver_step_rule(const srbm_batch* h, double* tol_step, double* start_mu);
 /* The library carries the kernels of the RTI path twice (same sources): set 0, one instance per CU (512 threads, the normal matrix of the solve in
@@ -246,6 +247,8 @@ int srbm_inverse_kinematics(srbm_batch* h, const double* state, const double* ee
  * force_des[batch][4][3] = Trajectory::GetForce(ee, time).  status[batch]: 0 ok, 1 IK not converged, 2 time outside the trajectory
  * ("bad interp." / spline range: the reference throws) */
 int srbm_get_targets_from_traj(srbm_batch* h, const double* time, double* q_des, double* v_des, double* force_des, int* status);
+/* ... on device pointers (same shapes): ONE launch on the batch's stream, no copy, no synchronisation */
+int srbm_get_targets_from_traj_dev(srbm_batch* h, const double* time_dev, double* q_des_dev, double* v_des_dev, double* force_des_dev, int* status_dev);
 
 /* QPControl (controllers/qp_control.cpp): the 1 kHz whole-body inverse-dynamics QP, for every instance of the batch.
  * Model: the rigid bodies pinocchio builds from the URDF -- trunk, then FL FR RL RR x (hip, thigh, calf), links on fixed joints
@@ -266,6 +269,9 @@ int srbm_set_wbc_model(srbm_batch* h, const srbm_wbc_model* model);
  * qp_dump (may be NULL): the assembled QP in the reference's layout per instance: A[50][30], lb[50], ub[50], diag P[30], w[30]. */
 int srbm_qp_control(srbm_batch* h, const double* q, const double* v, const int* contact, const double* q_des, const double* v_des,
                     const double* force_des, double* control, double* qp_sol, int* status, double* qp_dump);
+/* ... on device pointers: control_dev[batch][36], qp_sol_dev[batch][30], status_dev[batch]; one launch, no copy, no synchronisation */
+int srbm_qp_control_dev(srbm_batch* h, const double* q_dev, const double* v_dev, const int* contact_dev, const double* q_des_dev, const double* v_des_dev,
+                        const double* force_des_dev, double* control_dev, double* qp_sol_dev, int* status_dev);
 
 /* ---- results (all copied to host) ---- */
 /* sizes[batch][8] = n, m, n_eq, n_ineq, n_force_vars, n_pos_vars, n_td_rows, n_force_samples */

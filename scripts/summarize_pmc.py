@@ -104,6 +104,63 @@ if 'SQ_LDS_BANK_CONFLICT' in S2:
     summ.update({'lds_bank_conflict_frac': S2['SQ_LDS_BANK_CONFLICT'] / S2['SQ_LDS_IDX_ACTIVE'] if S2.get('SQ_LDS_IDX_ACTIVE') else None,
                  'lds_active_frac_of_wave_cycles': (S2.get('SQ_ACTIVE_INST_LDS', 0.0) / S1['SQ_WAVE_CYCLES']) if S1.get('SQ_WAVE_CYCLES') else None,
                  'valu_busy_frac': (S2.get('SQ_ACTIVE_INST_VALU', 0.0) / S1['SQ_WAVE_CYCLES']) if S1.get('SQ_WAVE_CYCLES') else None})
+# ---- round 3: the other workloads / segments ----
+def kernel_stats(sub, out_name, title, bench_json=None):
+    f = find(sub, '*kernel_stats.csv')
+    if not f:
+        return
+    rows_ = list(csv.DictReader(open(f)))
+    with open(os.path.join(dst, out_name), 'w') as fh:
+        fh.write('# %s\n' % title)
+        b_ = bench_line(bench_json) if bench_json else None
+        if b_:
+            fh.write('# bench line of the same run: value %.0f %s, ms_per_step %.4f, workload: %s\n' % (b_['value'], b_['unit'], b_['ms_per_step'], b_['config']['workload'][:120]))
+            if 'gait' in b_:
+                fh.write('# gait segment of the same run: %s\n' % json.dumps({k: b_['gait'][k] for k in ('ms_per_step', 'rti_solves_per_s_incl_line_search', 'gait_steps_per_s', 'err_bits_all_steps', 'not_solved_all_steps')}))
+        fh.write('Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n')
+        for r in rows_:
+            fh.write('%s,%s,%s,%s,%s,%s,%s\n' % (r['Name'].split('(')[0], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']))
+
+
+kernel_stats('trace_D', 'D_kernel_stats.csv', 'rocprofv3 --kernel-trace --stats -- python3 bench.py --workload D --no-cpu-baseline --closed-loop-steps 0 (512 instances, N = 50: co-resident kernel set)', 'bench_D_under_rocprof.json')
+kernel_stats('trace_E', 'E_kernel_stats.csv', 'rocprofv3 --kernel-trace --stats -- python3 bench.py --workload E --no-cpu-baseline --closed-loop-steps 0 (128 instances, N = 40: LARGE build)', 'bench_E_under_rocprof.json')
+kernel_stats('trace_gait', 'gait_kernel_stats.csv', 'rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --closed-loop-steps 0 --wbc-ticks 0 (Config B region + the gait segment: 30 steps, 6 gait steps, 6 line searches)', 'bench_gait_under_rocprof.json')
+
+
+def counters_of(sub, kernel_sub):
+    path = find(sub, '*counter_collection.csv')
+    if not path:
+        return {}
+    per, n = {}, {}
+    for r in csv.DictReader(open(path)):
+        if kernel_sub in r['Kernel_Name']:
+            per[r['Counter_Name']] = per.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
+            n.setdefault(r['Counter_Name'], set()).add(int(r['Dispatch_Id']))
+    return {c: v / max(1, len(n[c])) for c, v in per.items()}, {c: len(v) for c, v in n.items()}
+
+
+extra = {}
+cd = counters_of('pmc_D_sq1', 'srbm_rti_fused')
+if cd:
+    c, nd = cd
+    gui = c.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
+    extra['config_D_co_resident'] = {'kernel': 'srbm_co::srbm_rti_fused_long (512 instances on 256 CUs)', 'dispatches_averaged': nd, 'raw_counters_per_launch': c,
+        'waves_launched_per_launch': c.get('SQ_WAVES'),
+        'occupancy_waves_per_cu': 4.0 * c['SQ_WAVE_CYCLES'] / (gui * 256) if gui and 'SQ_WAVE_CYCLES' in c else None,
+        'mfma_busy_frac': c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui * 256 * 4) if gui else None,
+        'wave_cycles_split': {k: c[k] / c['SQ_WAVE_CYCLES'] for k in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY') if k in c and c.get('SQ_WAVE_CYCLES')}}
+for kn in ('srbm_k_targets_from_traj', 'srbm_k_qp_control'):
+    c1 = counters_of('pmc_f3_sq1', kn); c2 = counters_of('pmc_f3_sq2', kn)
+    if c1 and c2:
+        a, na = c1; b_, nb = c2
+        gui = a.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
+        extra[kn] = {'dispatches_averaged': na, 'raw_counters_per_launch': {**a, **b_},
+                     'occupancy_waves_per_cu': 4.0 * a['SQ_WAVE_CYCLES'] / (gui * 256) if gui and 'SQ_WAVE_CYCLES' in a else None,
+                     'wave_cycles_split': {k: a[k] / a['SQ_WAVE_CYCLES'] for k in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY') if k in a and a.get('SQ_WAVE_CYCLES')},
+                     'valu_instructions_per_wave': b_.get('SQ_INSTS_VALU', 0.0) / a['SQ_WAVES'] if a.get('SQ_WAVES') else None,
+                     'lds_bank_conflict_frac': b_['SQ_LDS_BANK_CONFLICT'] / b_['SQ_LDS_IDX_ACTIVE'] if b_.get('SQ_LDS_IDX_ACTIVE') else None}
+if extra:
+    summ['other_kernels'] = extra
 json.dump(summ, open(os.path.join(dst, 'pmc_summary.json'), 'w'), indent=1)
 print(open(os.path.join(dst, 'timed_region.txt')).read())
 print(json.dumps({k: v for k, v in summ.items() if k != 'raw_counters_per_launch'}, indent=1))

@@ -121,6 +121,11 @@ def test_bench_gpus_flag_spawns_the_ranks():
     import json
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 512 and d['config']['records_gathered'] == 512 and d['config']['gather_ok']
+    # the same for the per-GPU share of BASELINE config 4 (512 instances x 2 ranks)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--workload', 'D'], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert d['n_gpus'] == 2 and d['config']['batch_per_gpu'] == 512 and d['config']['global_batch'] == 1024 and d['config']['records_gathered'] == 1024 and d['config']['gather_ok']
     # a world size that contradicts --gpus is refused, never reported as n_gpus = 1
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE='1', RANK='0'), timeout=300)

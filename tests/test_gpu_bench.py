@@ -3,6 +3,7 @@
 one rank), and the one JSON line it prints carries every field of the measurement contract."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -12,11 +13,16 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
 def test_bench_line_under_torchrun_with_the_collective_path():
     env = dict(os.environ, SRBM_BENCH_FORCE_DIST='1')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', '29577',
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
            os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '2', '--repeats', '2', '--gait-steps', '10', '--closed-loop-steps', '4', '--wbc-ticks', '3']
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -40,3 +46,39 @@ def test_bench_line_under_torchrun_with_the_collective_path():
         assert k in cb, k
     assert cb['kind'] == 'port' and cb['cores'] == 1 and cb['value'] > 10
     assert d['gait']['err_bits_all_steps'] == 0 and d['closed_loop']['plant_finite'] and d['wbc']['finite']
+
+
+def run_bench(*args):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'SRBM_BENCH_FORCE_DIST')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(args), capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_config_d_full_per_gpu_share_through_the_bench():
+    """BASELINE config 4's per-GPU share AT FULL SIZE -- 512 instances, N = 50, push distribution -- through bench.py --workload D as a child
+    process (the protocol whose numbers DESIGN.md quotes): every timed solve accounted for through the sticky accumulators, no error bit, the
+    batch on the co-resident kernel set, and the only solves that do not end Solved belong to the pushed instances whose QPs the ORACLE's solver
+    finds primal infeasible as well (tests/test_gpu_parity.py::test_infeasible_qps_of_the_pushed_configuration_are_infeasible_for_the_oracle_too
+    exports exactly those QPs and solves them with the restatement)."""
+    d = run_bench('--workload', 'D', '--no-cpu-baseline', '--closed-loop-steps', '0')
+    c = d['config']
+    assert c['batch_per_gpu'] == 512 and c['num_nodes'] == 50 and c['records_gathered'] == 512
+    assert c['timed_solves'] == 512 * d['steps'] * d['repeats'] and c['err_bits_all_timed_steps'] == 0 and c['max_iter_in_timed_solves'] == 0
+    assert c['kernel_set'] == 1
+    assert set(c['instances_with_a_solve_not_solved_rank0']) <= {150, 441}, c['instances_with_a_solve_not_solved_rank0']
+    assert c['not_solved_in_timed_solves'] <= 2 * d['steps'] * d['repeats']
+    assert d['value'] > 4e4, d['value']
+    assert d['roofline']['kernel'].startswith('srbm_rti_fused_long')
+
+
+def test_config_e_full_per_gpu_share_through_the_bench():
+    """BASELINE config 5's per-GPU share (128 instances, N = 40: 232 spline variables, the LARGE-capacity build) through bench.py --workload E: every
+    timed solve Solved, no error bit"""
+    d = run_bench('--workload', 'E', '--no-cpu-baseline', '--closed-loop-steps', '0')
+    c = d['config']
+    assert c['batch_per_gpu'] == 128 and c['num_nodes'] == 40 and c['records_gathered'] == 128
+    assert c['timed_solves'] == 128 * d['steps'] * d['repeats'] and c['all_solved'] and c['err_bits_all_timed_steps'] == 0
+    assert '(LARGE build)' in d['roofline']['kernel'] and d['value'] > 5e3

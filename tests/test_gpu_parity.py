@@ -277,6 +277,7 @@ def test_fused_kernel_equals_one_launch_per_phase():
         g = host.BatchMPC(cfg, B)
         g.set_state_trajectory_warm_start(states)
         g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
+        g.set_solver_step_rule(g.solver_step_rule()[0], 0.0)      # (the lower-start attempt belongs to the K-step launch alone: off on both sides)
         g.create_initial_run(states, ees)
         (g.rti_advance if fused else g.rti_advance_unfused)(0, 7)
         g.synchronize()

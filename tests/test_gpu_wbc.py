@@ -95,3 +95,39 @@ def test_full_batch_controller_properties():
     assert st[0] == 0 and np.abs(sol[0, :18]).max() < 0.5             # (almost) no acceleration: the weight is carried
     assert abs(sol[0, 18:].reshape(4, 3)[:, 2].sum() - cfg['mass'] * 9.81) < 1.0
     assert np.all(ctl[0, 24:].reshape(4, 3)[:, 2] != 0)                # the calf joints work against gravity
+
+
+def test_device_pointer_entries_of_the_control_tick_equal_the_host_pointer_entries():
+    """srbm_get_targets_from_traj_dev / srbm_qp_control_dev: the same kernels on buffers that are already in HBM (here: torch tensors), one launch
+    each and no PCIe hop -- bit-identical to the host-pointer entries"""
+    import torch
+    B = 32
+    cfg, q, v, q_des, v_des, rng = make(B, seed=21)
+    from bench import config_b_instance
+    states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees).reshape(B, 12)
+    g = host.BatchMPC(cfg, B)
+    g.set_state_trajectory_warm_start(states)
+    g.create_initial_run(states, ees)
+    t0 = g.get_trajectory(0, 1)[0].init_time + 2e-3
+    q0 = np.tile(np.array(cfg['init_config'], float), (B, 1))
+    qh, vh, fh, sth = g.get_targets_from_traj(t0, q0)
+    dev = lambda a, dt=torch.float64: torch.tensor(np.ascontiguousarray(a), dtype=dt, device='cuda')
+    tq, tv, tf, ts = dev(q0), torch.zeros((B, 18), dtype=torch.float64, device='cuda'), torch.zeros((B, 12), dtype=torch.float64, device='cuda'), torch.zeros(B, dtype=torch.int32, device='cuda')
+    tt = dev(np.full(B, t0))
+    g.get_targets_from_traj_dev(tt.data_ptr(), tq.data_ptr(), tv.data_ptr(), tf.data_ptr(), ts.data_ptr())
+    g.synchronize()
+    assert np.array_equal(tq.cpu().numpy(), qh) and np.array_equal(tv.cpu().numpy(), vh) and np.array_equal(tf.cpu().numpy().reshape(B, 4, 3), fh)
+    assert np.array_equal(ts.cpu().numpy(), sth)
+    contact = np.array([CONTACTS[b % 3] for b in range(B)], np.int32)
+    fdes = np.zeros((B, 12))
+    for b in range(B):
+        nc = contact[b].sum()
+        fdes[b, :3 * nc] = np.tile([0, 0, cfg['mass'] * 9.81 / nc], nc)
+    ctl, sol, st, iters = g.qp_control(q, v, contact, q_des, v_des, fdes)
+    tc, tsol, tst = torch.zeros((B, 36), dtype=torch.float64, device='cuda'), torch.zeros((B, 30), dtype=torch.float64, device='cuda'), torch.zeros(B, dtype=torch.int32, device='cuda')
+    ins = [dev(q), dev(v), dev(contact, torch.int32), dev(q_des), dev(v_des), dev(fdes)]
+    g.qp_control_dev(*[a.data_ptr() for a in ins], tc.data_ptr(), tsol.data_ptr(), tst.data_ptr())
+    g.synchronize()
+    assert np.array_equal(tc.cpu().numpy(), ctl) and np.array_equal(tsol.cpu().numpy(), sol)
+    assert np.array_equal(tst.cpu().numpy() & 0xff, st) and np.array_equal(tst.cpu().numpy() >> 8, iters)
