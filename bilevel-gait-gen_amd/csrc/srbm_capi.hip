@@ -477,6 +477,7 @@ static int alloc_batch(srbm_batch* h, hipStream_t borrowed_stream) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_rti_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_rti_fused_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_normal_matrix), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k_gait_sensitivity), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KG_DYN_LDS_BYTES));
 #ifdef SRBM_LARGE
     static_assert(sizeof(K1Shared) <= 160 * 1024 && sizeof(K2Shared) <= 160 * 1024 && sizeof(K4Shared) <= 160 * 1024, "working sets fit the LDS of a CU");
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k1_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(K1Shared)));
@@ -678,7 +679,9 @@ int srbm_get_real_time_update_dev(srbm_batch* h, const double* state_dev, const 
     return launch_step(h);
 }
 static int launch_fused(srbm_batch* h, int first_index, int steps, SrbmPlantArgs pl) {
-    pl.tol_step = h->hp.tol_step; pl.start_mu = h->hp.start_mu;
+    // (the lower-start attempt rests on the linearisation point being close to the new minimiser: true for the open-loop protocol, whose state IS
+    //  node 1 of the plan; under a plant -- integration error every step, pushes -- it is repeated too often to pay: closed loop 62 k it/s with, 80 k without)
+    pl.tol_step = h->hp.tol_step; pl.start_mu = pl.plant ? 0.0 : h->hp.start_mu;
     HIPCHK(hipSetDevice(h->device));
     if (upload_params(h)) return -1;
     if (steps == 0) return 0;
@@ -913,7 +916,7 @@ int srbm_gait_compute_sensitivity(srbm_gait* g) {
     HIPCHK(hipSetDevice(h->device));
     if (upload_params(h)) return -1;
     hipLaunchKernelGGL(srbm_k3_normal_matrix, dim3(h->batch), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works);
-    hipLaunchKernelGGL(srbm_k_gait_sensitivity, dim3(h->batch), dim3(KG_THREADS), 0, h->stream, h->dp, h->insts, h->works, g->gw);
+    hipLaunchKernelGGL(srbm_k_gait_sensitivity, dim3(h->batch), dim3(KG_THREADS), KG_DYN_LDS_BYTES, h->stream, h->dp, h->insts, h->works, g->gw);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -65,8 +65,8 @@ int srbm_set_solver_tolerances(srbm_batch* h, double tol_gap_abs, double tol_gap
  * minimiser of the QP -- is below tol_step * max(1, |u|_inf); the iterate then takes that step (what is left is <= 0.2 tol_step).  start_mu > 0:
  * every solve is first attempted from the linearisation point (the shifted solution of the previous RTI step) with slacks h - G u and perfectly
  * centred multipliers lambda = start_mu / s -- five to six decades further down the central path than Clarabel's starting point -- and repeated from the
- * standard point unless the attempt ends through the step rule (device-resident K-step launches only -- srbm_rti_advance, srbm_closed_loop_advance --
- * where a repeated attempt of one instance is averaged over its K steps; a one-step launch would wait for it every time).  Both 0: exactly the gap
+ * standard point unless the attempt ends through the step rule (the device-resident open-loop launch srbm_rti_advance only: there a repeated
+ * attempt of one instance is averaged over its K steps -- a one-step launch would wait for it every time -- and the state is node 1 of the plan).  Both 0: exactly the gap
  * criterion of srbm_set_solver_tolerances.
  * The bilevel step differentiates the KKT system of a solve and needs its duals at the reference's tolerance: srbm_gait_rti_advance runs that
  * one solve of its protocol at the gap criterion by itself; a caller that drives the protocol (srbm_get_real_time_update, then

@@ -98,9 +98,24 @@ def test_full_batch_controller_properties():
 
 
 def test_device_pointer_entries_of_the_control_tick_equal_the_host_pointer_entries():
-    """srbm_get_targets_from_traj_dev / srbm_qp_control_dev: the same kernels on buffers that are already in HBM (here: torch tensors), one launch
-    each and no PCIe hop -- bit-identical to the host-pointer entries"""
-    import torch
+    """srbm_get_targets_from_traj_dev / srbm_qp_control_dev: the same kernels on buffers that are already in HBM (hipMalloc'ed here through the HIP
+    runtime), one launch each and no PCIe hop -- bit-identical to the host-pointer entries"""
+    import ctypes as C
+    hip = C.CDLL('libamdhip64.so')
+
+    class Dev:
+        def __init__(self, a):
+            self.a = np.ascontiguousarray(a); self.p = C.c_void_p()
+            assert hip.hipMalloc(C.byref(self.p), C.c_size_t(self.a.nbytes)) == 0
+            assert hip.hipMemcpy(self.p, self.a.ctypes.data_as(C.c_void_p), C.c_size_t(self.a.nbytes), 1) == 0      # hipMemcpyHostToDevice (synchronous)
+
+        def get(self):
+            out = np.empty_like(self.a)
+            assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), self.p, C.c_size_t(self.a.nbytes), 2) == 0
+            return out
+
+        def __del__(self):
+            hip.hipFree(self.p)
     B = 32
     cfg, q, v, q_des, v_des, rng = make(B, seed=21)
     from bench import config_b_instance
@@ -112,22 +127,19 @@ def test_device_pointer_entries_of_the_control_tick_equal_the_host_pointer_entri
     t0 = g.get_trajectory(0, 1)[0].init_time + 2e-3
     q0 = np.tile(np.array(cfg['init_config'], float), (B, 1))
     qh, vh, fh, sth = g.get_targets_from_traj(t0, q0)
-    dev = lambda a, dt=torch.float64: torch.tensor(np.ascontiguousarray(a), dtype=dt, device='cuda')
-    tq, tv, tf, ts = dev(q0), torch.zeros((B, 18), dtype=torch.float64, device='cuda'), torch.zeros((B, 12), dtype=torch.float64, device='cuda'), torch.zeros(B, dtype=torch.int32, device='cuda')
-    tt = dev(np.full(B, t0))
-    g.get_targets_from_traj_dev(tt.data_ptr(), tq.data_ptr(), tv.data_ptr(), tf.data_ptr(), ts.data_ptr())
+    tt, tq, tv, tf, ts = Dev(np.full(B, t0)), Dev(q0), Dev(np.zeros((B, 18))), Dev(np.zeros((B, 12))), Dev(np.zeros(B, np.int32))
+    g.get_targets_from_traj_dev(tt.p.value, tq.p.value, tv.p.value, tf.p.value, ts.p.value)
     g.synchronize()
-    assert np.array_equal(tq.cpu().numpy(), qh) and np.array_equal(tv.cpu().numpy(), vh) and np.array_equal(tf.cpu().numpy().reshape(B, 4, 3), fh)
-    assert np.array_equal(ts.cpu().numpy(), sth)
+    assert np.array_equal(tq.get(), qh) and np.array_equal(tv.get(), vh) and np.array_equal(tf.get().reshape(B, 4, 3), fh) and np.array_equal(ts.get(), sth)
     contact = np.array([CONTACTS[b % 3] for b in range(B)], np.int32)
     fdes = np.zeros((B, 12))
     for b in range(B):
         nc = contact[b].sum()
         fdes[b, :3 * nc] = np.tile([0, 0, cfg['mass'] * 9.81 / nc], nc)
     ctl, sol, st, iters = g.qp_control(q, v, contact, q_des, v_des, fdes)
-    tc, tsol, tst = torch.zeros((B, 36), dtype=torch.float64, device='cuda'), torch.zeros((B, 30), dtype=torch.float64, device='cuda'), torch.zeros(B, dtype=torch.int32, device='cuda')
-    ins = [dev(q), dev(v), dev(contact, torch.int32), dev(q_des), dev(v_des), dev(fdes)]
-    g.qp_control_dev(*[a.data_ptr() for a in ins], tc.data_ptr(), tsol.data_ptr(), tst.data_ptr())
+    ins = [Dev(q), Dev(v), Dev(contact), Dev(q_des), Dev(v_des), Dev(fdes)]
+    tc, tsol, tst = Dev(np.zeros((B, 36))), Dev(np.zeros((B, 30))), Dev(np.zeros(B, np.int32))
+    g.qp_control_dev(*[a.p.value for a in ins], tc.p.value, tsol.p.value, tst.p.value)
     g.synchronize()
-    assert np.array_equal(tc.cpu().numpy(), ctl) and np.array_equal(tsol.cpu().numpy(), sol)
-    assert np.array_equal(tst.cpu().numpy() & 0xff, st) and np.array_equal(tst.cpu().numpy() >> 8, iters)
+    assert np.array_equal(tc.get(), ctl) and np.array_equal(tsol.get(), sol)
+    assert np.array_equal(tst.get() & 0xff, st) and np.array_equal(tst.get() >> 8, iters)
