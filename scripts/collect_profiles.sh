@@ -42,5 +42,7 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES 
 echo "pmc_f3_sq1 rc=$?" >> $OUT/passes.log
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_f3_sq2 -o pmc --output-format csv -- python3 $CMD_F3 > $OUT/bench_pmc_f3_sq2.json 2> $OUT/pmc_f3_sq2.err
 echo "pmc_f3_sq2 rc=$?" >> $OUT/passes.log
+python3 scripts/dev_prof.py > $OUT/phase_shares.txt 2> $OUT/phase_shares.err
+echo "dev_prof rc=$?" >> $OUT/passes.log
 cat $OUT/passes.log
 find $OUT -name "*.csv" | sort
