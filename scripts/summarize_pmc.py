@@ -54,9 +54,13 @@ timed = rows[-repeats:]
 ms = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in timed]
 with open(os.path.join(dst, 'timed_region.txt'), 'w') as f:
     f.write('%s: %d launches in the trace (1 warm-up launch of %d steps + %d timed regions of %d steps)\n' % (KERNEL, len(rows), pb['warmup'], repeats, steps))
-    f.write('timed-region launches, kernel trace:  %s ms   mean %.3f ms = %.4f ms per RTI step\n' % (' '.join('%.3f' % v for v in ms), sum(ms) / len(ms), sum(ms) / len(ms) / steps))
-    f.write('live HIP-event figure of the same run (bench.py roofline.avg_launch_ms): %.3f ms\n' % pb['roofline']['avg_launch_ms'])
+    med = sorted(ms)[len(ms) // 2]
+    f.write('timed-region launches, kernel trace:  %s ms   median %.3f ms = %.4f ms per RTI step (mean %.3f; the first region follows the cold start)\n' % (' '.join('%.3f' % v for v in ms), med, med / steps, sum(ms) / len(ms)))
+    f.write('live HIP-event figures of the same run (bench.py roofline.launch_ms_all): %s ms; the MEDIAN region is what `value` and `roofline` describe: %.3f ms\n' % (' '.join('%.3f' % v for v in pb['roofline'].get('launch_ms_all', [])), pb['roofline']['avg_launch_ms']))
     f.write('unprofiled run: avg_launch_ms %.3f, ms_per_step %.4f, value %.0f it/s\n' % (ub['roofline']['avg_launch_ms'], ub['ms_per_step'], ub['value']))
+
+
+MED_IDX = sorted(range(len(ms)), key=lambda i: ms[i])[len(ms) // 2]
 
 
 def counters(sub):
@@ -69,17 +73,19 @@ def counters(sub):
         if KERNEL in r['Kernel_Name']:
             d = per.setdefault(r['Counter_Name'], {})
             d[int(r['Dispatch_Id'])] = d.get(int(r['Dispatch_Id']), 0.0) + float(r['Counter_Value'])
+    # the launch `value` and `roofline` describe: the MEDIAN region of the timed five (same deterministic workload in every pass, so the same launch)
     out = {}
     for c, d in per.items():
         ids = sorted(d)[-repeats:]
-        out[c] = sum(d[i] for i in ids) / len(ids)
+        out[c] = d[ids[MED_IDX]] if MED_IDX < len(ids) else sum(d[i] for i in ids) / len(ids)
     return out
 
 
 F, W, S1, S2 = counters('pmc_fetch'), counters('pmc_write'), counters('pmc_sq1'), counters('pmc_sq2')
 summ = {'kernel': KERNEL, 'round': rnd, 'kernel_source_sha': bench.kernel_source_sha(), 'steps_per_launch': steps, 'timed_launches': repeats,
         'command': 'rocprofv3 --pmc <one pass per counter group, no other tracing> -- python3 bench.py --no-cpu-baseline --gait-steps 0 --closed-loop-steps 0 --wbc-ticks 0',
-        'kernel_trace_ms_per_launch': sum(ms) / len(ms), 'hip_event_ms_per_launch_same_run': pb['roofline']['avg_launch_ms'],
+        'launch_described': 'the median region of the timed five (index %d): counters, duration and the bench line all refer to it' % MED_IDX,
+        'kernel_trace_ms_per_launch': ms[MED_IDX], 'hip_event_ms_per_launch_same_run': pb['roofline']['avg_launch_ms'],
         'raw_counters_per_launch': {**F, **W, **S1, **S2}}
 if 'FETCH_SIZE' in F and 'WRITE_SIZE' in W:
     hbm = (2.0 * F['FETCH_SIZE'] + W['WRITE_SIZE']) * 1024.0
@@ -94,7 +100,7 @@ if 'SQ_WAVE_CYCLES' in S1:
     # cycles (guide, 's_memtime tick vs SQ PMC units'); GRBM_GUI_ACTIVE is summed over the 8 XCDs
     gui = S1.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
     summ.update({'gpu_cycles_per_launch': gui,
-                 'effective_clock_GHz': gui / (sum(ms) / len(ms) * 1e6) if gui else None,
+                 'effective_clock_GHz': gui / (ms[MED_IDX] * 1e6) if gui else None,
                  'mfma_busy_cycles_per_launch': S1.get('SQ_VALU_MFMA_BUSY_CYCLES'),
                  # 256 CUs x 4 SIMDs each could be busy for every GPU cycle of the launch
                  'mfma_busy_frac': S1.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui * 256 * 4) if gui else None,
