@@ -41,7 +41,7 @@ struct srbm_batch {
     size_t k3_lds = 0;
     // kernel set: 0 = standard (512 threads, normal matrix in LDS, one instance per CU), 1 = co-resident (srbm_co.h).  Chosen by the batch size
     // at creation (more instances than CUs -> co-resident), srbm_set_kernel_set overrides.  dp_co: the parameters with the co-resident LDS size
-    int kernel_set = 0;
+    int kernel_set = 0, n_cu = 0;
     bool co_available = false;
     SrbmParams* dp_co = nullptr;
     size_t k3_lds_co = 0;
@@ -301,6 +301,8 @@ static int launch_step(srbm_batch* h, bool exact = false) {
     if (upload_params(h)) return -1;
     // (start_mu only in the fused K-step launches: the lower-start attempt trades a shorter mean for a longer tail, and a one-step launch ends with
     //  the slowest instance of the batch -- srbm_k3_ipm.hiph)
+    //  (Tried for the 10 x batch candidates of a gait line search, where dynamic workgroup scheduling evens out the tail: a candidate's linearisation
+    //  point belongs to ANOTHER contact schedule -- 17-35 % of the attempts are repeated, the gait segment goes from 8.3 to 10.4-11.8 ms per step.)
     const double tol_step = exact ? 0.0 : h->hp.tol_step, start_mu = 0.0;
     const int B = h->batch;
 #ifndef SRBM_LARGE
@@ -489,6 +491,7 @@ static int alloc_batch(srbm_batch* h, hipStream_t borrowed_stream) {
         // the co-resident set: available when the horizon's working set fits half a CU; chosen when the batch has more instances than the GPU has CUs
         int n_cu = 0;
         HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
+        h->n_cu = n_cu;
         h->co_available = srbm_co_configure(h->hp.N, &h->k3_lds_co) == 0;
         if (h->co_available) HIPCHK(hipMalloc(&h->dp_co, sizeof(SrbmParams)));
         h->kernel_set = (h->co_available && n_cu > 0 && h->batch > n_cu) ? 1 : 0;
@@ -560,6 +563,7 @@ int srbm_batch_clone(const srbm_batch* src, srbm_batch** out) {
              hipMalloc(&h->d_push_impulse, sizeof(double) * 6 * B) == hipSuccess && cp(h->d_plant, src->d_plant, sizeof(double) * 13 * B) &&
              cp(h->d_push_time, src->d_push_time, sizeof(double) * B) && cp(h->d_push_impulse, src->d_push_impulse, sizeof(double) * 6 * B);
     }
+    if (ok && src->d_wbc) ok = hipMalloc(&h->d_wbc, sizeof(SrbmWbcParams)) == hipSuccess && cp(h->d_wbc, src->d_wbc, sizeof(SrbmWbcParams));      // (a clone carries the complete state)
     if (!ok) { fail("srbm_batch_clone: device copy failed"); return bail(); }
     if (upload_params(h)) return bail();
     if (hipStreamSynchronize(h->stream) != hipSuccess) { fail("srbm_batch_clone: synchronisation failed"); return bail(); }

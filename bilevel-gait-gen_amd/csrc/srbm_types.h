@@ -81,7 +81,7 @@ typedef struct SrbmInst {
     int status, qp_iters, n, m, n_eq, n_ineq, nfv, npv, n_td, n_samples, err, run_num;
     double acc_iters, acc_flops;                  /* running totals: IPM iterations, algorithmic flops (SURVEY.md 8d formula) */
     /* sticky accumulators over ALL solves since srbm_clear_status_accumulators: `err` / `status` describe the last solve only
-       (kernel 1 restarts them), these keep every error bit raised and count the solves by outcome; cost_sum / n_solves is
+       (kernel 1 restarts them), these keep every error bit raised and count the solves by outcome; cost_sum / run_num is
        MPC::GetAvgCost (mpc.cpp:991-998: mean of the cost_ entries RecordStats pushes, one per solve) */
     double cost_sum;
     double merit_dd;                              /* directional derivative of the L1 merit along the step of the last solve (mpc.cpp:783-788; the 'Merit dd' column of the statistics log) */

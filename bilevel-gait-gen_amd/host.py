@@ -222,9 +222,16 @@ class BatchMPC:
             self._chk(self.L.srbm_set_wbc_model(self.h, C.byref(w)))
 
     def close(self):
+        """srbm_batch_destroy.  A batch that gait handles still borrow is NOT released by the library (return code -1): the handle is kept, so that
+        it is released once the optimiser is gone, instead of leaking the device batch silently"""
         if self.h:
-            self.L.srbm_batch_destroy(self.h)
-            self.h = C.c_void_p()
+            for g in list(getattr(self, '_gait_handles', [])):        # optimisers created on this batch go first
+                g.close()
+            if self.L.srbm_batch_destroy(self.h) == 0:
+                self.h = C.c_void_p()
+            else:
+                import warnings
+                warnings.warn('srbm_batch_destroy refused: ' + self.L.srbm_last_error().decode())
 
     def __del__(self):
         try:
@@ -469,7 +476,7 @@ class BatchMPC:
         s = self.stats()[inst]
         merit, merit_dd = self.merit()
         vals = ['%d' % solve_number, '%g' % time_ms, '%g' % s[2], '%g' % s[3], '%g' % s[0], '%g' % s[1], '%g' % merit[inst], '%g' % merit_dd[inst],
-                SOLVE_TYPE_NAMES.get(int(st[inst]), 'Other'), '%g' % self.qp_cost()[inst]]
+                SOLVE_TYPE_NAMES.get(int(st[inst]), 'Other'), '%g' % s[1]]       # last column: cost_ = GetCostValue(prev_qp_sol), the same value as 'Cost' (mpc.cpp:809, msrb.cpp:183-184)
         fh.write(''.join(v.ljust(cw) for v in vals) + '\n')
 
     # ---- measurement aids ----
@@ -579,12 +586,19 @@ class BatchGaitOptimizer:
         self.L = mpc.L
         self.g = C.c_void_p()
         mpc._chk(self.L.srbm_gait_create(mpc.h, C.byref(self.g)))
+        import weakref
+        if not hasattr(mpc, '_gait_handles'):
+            mpc._gait_handles = weakref.WeakSet()
+        mpc._gait_handles.add(self)          # BatchMPC.close() releases the optimisers that borrow it first
+
+    def close(self):
+        if self.g:
+            self.L.srbm_gait_destroy(self.g)
+            self.g = None
 
     def __del__(self):
         try:
-            if self.g:
-                self.L.srbm_gait_destroy(self.g)
-                self.g = None
+            self.close()
         except Exception:
             pass
 

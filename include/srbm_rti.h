@@ -303,7 +303,8 @@ int srbm_get_knots(srbm_batch* h, int inst, double* times, int* kinds, int* nk, 
  * (rows/cols as SURVEY.md Appendix A): A[m][n], b[m], P[n][n], q[n].  Debug / parity-test aid. */
 int srbm_export_qp(srbm_batch* h, int inst, double* A, double* b, double* P, double* q);
 /* result records for collection across GPUs (one RCCL all-gather in bench.py): out_dev[batch][ld] on
- * the handle's stream.  Layout of one record (doubles), NX = 12 (N+1) + 160, NM = 12 (N+1) + 6*120 + 16 (N-3) + 16:
+ * the handle's stream.  Layout of one record (doubles), NX = 12 (N+1) + n_u_max, NM = 12 (N+1) + 6 * samples_max + 16 (N-3) + 16 with the capacities of the loaded build
+ * (srbm_get_capacity: 160 / 120 in the standard build, 240 / 200 in the LARGE one):
  *   [0..8)  status, n, m, cost, alpha, err (sticky bits since the last clear), qp_iters, init_time
  *   [8 .. 8+NX)           x[0..n)   primal (prev_qp_sol), zero padded
  *   [8+NX .. 8+NX+NM)     z[0..m)   dual vector in the reference's row order, zero padded

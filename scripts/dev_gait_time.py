@@ -9,7 +9,7 @@ FREQ, B, STEPS = 5, 256, 30
 cfg = host.load_config('a1_gait_opt_config', num_nodes=20, integrator_dt=0.05)
 sc, ec = zip(*[bench.config_c_instance(cfg, b) for b in range(B)])
 sc, ec = np.array(sc), np.array(ec).reshape(B, 12)
-for rule in ((1e-5, 0.0), (1e-5, 10.0), (0.0, 0.0)):
+for rule in ((1e-5, 0.0), (1e-5, 0.1)):
     for ks in (1,):
         gm = host.BatchMPC(cfg, B)
         gm.set_state_trajectory_warm_start(sc)

@@ -457,12 +457,13 @@ def test_config_b_all_instances_against_oracle_fixture():
             # after one solve grows along the flat directions of the weakly convex QP.  The bulk stays within the tolerance; the
             # tail is path divergence, bounded here and ABSENT in tests/test_gpu_resync.py, where both sides linearise at the
             # same point (strict 1e-4 for every instance and step there).
-            assert e < 20 * REL_TOL, (i, b, e)
+            assert e < 10 * REL_TOL, (i, b, e)
             assert stats[b, 4] <= 60, (i, b, stats[b, 4])       # no crawling: launch time is the slowest instance's
     assert n_inf >= 4 and alive.sum() >= 240     # the seeded batch does contain infeasible cold starts; the rest stays in
     errs = np.array(errs)
     print('own-path full-vector errors: median %.1e  p99 %.1e  max %.1e  > tol: %d of %d' % (np.median(errs), np.percentile(errs, 99), errs.max(), (errs >= REL_TOL).sum(), len(errs)))
-    assert (errs < REL_TOL).mean() >= 0.98
+    # distribution recorded in round 2 (1004 comparisons): median 1e-7, p99 3e-5, one solve above the tolerance (2.5e-4)
+    assert (errs < REL_TOL).mean() >= 0.98 and np.percentile(errs, 99) < REL_TOL and errs.max() < 1e-3
 
 
 def test_capacity_overflow_fails_loudly():

@@ -143,3 +143,23 @@ def test_device_pointer_entries_of_the_control_tick_equal_the_host_pointer_entri
     g.synchronize()
     assert np.array_equal(tc.get(), ctl) and np.array_equal(tsol.get(), sol)
     assert np.array_equal(tst.get() & 0xff, st) and np.array_equal(tst.get() >> 8, iters)
+
+
+def test_a_clone_carries_the_whole_body_model_and_close_releases_borrowers_first():
+    """srbm_batch_clone copies the complete state, the whole-body model included (round 2: a clone failed srbm_qp_control with "whole-body model
+    has not been set"); BatchMPC.close() releases the gait optimisers that borrow the batch before the batch (round 2: the library refused the
+    destroy, the binding dropped its handle and the device batch leaked)"""
+    B = 4
+    cfg, q, v, q_des, v_des, rng = make(B, seed=5)
+    contact = np.ones((B, 4), np.int32)
+    fdes = np.tile([0, 0, cfg['mass'] * 9.81 / 4], (B, 4))
+    g = host.BatchMPC(cfg, B)
+    a = g.qp_control(q, v, contact, q_des, v_des, fdes)
+    c = g.clone()
+    b = c.qp_control(q, v, contact, q_des, v_des, fdes)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    gait = host.BatchGaitOptimizer(g)
+    g.close()
+    assert not g.h and gait.g is None
+    c.close()
+    assert not c.h
