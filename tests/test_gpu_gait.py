@@ -122,7 +122,11 @@ def test_kkt_sensitivity(cfgname, nsteps):
     A, bvec, P, q = g.export_qp(0)
     z, s = g.dual_solution()
     sol, live, lam = as_coded_sensitivity(A, P, q, g.qp_solution()[0, :n], z[0], s[0], nx, mi)
-    assert np.abs(dz - sol[:n]).max() <= 1e-6 * max(1.0, np.abs(sol[:n]).max())
+    # scale: the solution x* -- what the gradient consumes is dq = dz + x* (part 2), and with exact complementarity dz itself is zero.  The
+    # as-coded matrix carries 1/s_i-sized pivots on the active rows, so BOTH dense solves return rounding noise in dz whose size depends on
+    # where the interior-point path stopped: over builds that differ in rounding only (scripts/dev_sens_dbg.py) the two disagree by
+    # 1e-9 ... 6e-6 at |x*| = 1.4e2 ... 1.6e2, i.e. <= 4e-8 of the scale used here; the block-row residuals below are the sharp check.
+    assert np.abs(dz - sol[:n]).max() <= 1e-7 * max(1.0, np.abs(xs_full := g.qp_solution()[0, :n]).max())
     assert np.abs(dn - sol[n + mi:]).max() <= 1e-6 * max(1.0, np.abs(sol[n + mi:]).max())
     # dlam_i = -(G dz)_i / s_i amplifies rounding by 1/s_i on active rows, in any implementation: check it through the
     # residuals of the three block rows instead of entry by entry
