@@ -368,7 +368,7 @@ __global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_solve(int n, const do
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
     dn_trtri(M, n);
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
-    dn_solve_inv(0, n, (int)(xv - dbg_smem2), (int)(tv - dbg_smem2), -1, 0
+    dn_solve_inv(0, n, (int)(xv - dbg_smem2), (int)(tv - dbg_smem2), -1, 0, 0
 #ifdef SRBM_M_GLOBAL
                  , M
 #endif
