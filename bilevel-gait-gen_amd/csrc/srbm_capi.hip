@@ -395,6 +395,59 @@ __global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_cholesky(int n, const
     for (int e = threadIdx.x; e < np; e += DN_THREADS) Lout[(size_t)blockIdx.x * np + e] = M[e];
     if (threadIdx.x == 0) nreg_out[blockIdx.x] = nreg | ((int)min((long long)0x7fffff, (t1 - t0) >> 4) << 8);   // bits 8..: ticks / 16 (diagnostic)
 }
+// unit-test hook for the dense phase on a subset of the columns (what the IPM does with the pinned position variables): tiles loaded through
+// the column map, factor + inverse of the mapped block, solve with the gather / scatter through the map; unmapped entries of x keep rhs
+__global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_solve_mapped(int n, int nc, const int* __restrict__ map, const double* __restrict__ Min,
+                                                                      const double* __restrict__ rhs, double* __restrict__ xout, int* __restrict__ nreg_out) {
+    extern __shared__ double dbg_smem3[];
+    const int np = n * (n + 1) / 2;
+    double* M = dbg_smem3;
+    double* panel = dbg_smem3 + (size_t)SRBM_NUMAX * (SRBM_NUMAX + 1) / 2;
+    double* xv = panel + DN_PANEL_DOUBLES;
+    double* tv = xv + SRBM_NUMAX;
+    double* xc = tv + SRBM_NUMAX;
+    int* imap = reinterpret_cast<int*>(xc + SRBM_NUMAX);
+    const double* src = Min + (size_t)blockIdx.x * np;
+    for (int e = threadIdx.x; e < np; e += DN_THREADS) M[e] = src[e];
+    for (int e = threadIdx.x; e < n; e += DN_THREADS) xv[e] = rhs[(size_t)blockIdx.x * n + e];
+    for (int e = threadIdx.x; e < nc; e += DN_THREADS) imap[e] = map[e];
+    __syncthreads();
+    DnTiles T;
+    int nreg = 0;
+    dn_load_packed(T, M, nc, imap);
+    dn_cholesky(T, M, nc, panel, &nreg);
+    chol_invert_diag_blocks(M, nc);
+    dn_trtri(M, nc);
+    dn_solve_inv(0, nc, (int)(xv - dbg_smem3), (int)(tv - dbg_smem3), (int)(reinterpret_cast<double*>(imap) - dbg_smem3), (int)(xc - dbg_smem3), 0
+#ifdef SRBM_M_GLOBAL
+                 , M
+#endif
+    );
+    for (int e = threadIdx.x; e < n; e += DN_THREADS) xout[(size_t)blockIdx.x * n + e] = xv[e];
+    if (threadIdx.x == 0) nreg_out[blockIdx.x] = nreg;
+}
+int srbm_debug_solve_mapped(int n, int nc, const int* map, int count, const double* M_packed, const double* rhs, double* x, int* nreg) {
+#ifdef SRBM_LARGE
+    return fail("srbm_debug_solve_mapped: the unit-test hooks of the dense blocks exist in the standard build only");
+#endif
+    if (n <= 0 || n > SRBM_NUMAX || nc <= 0 || nc > n || count <= 0 || !map || !M_packed || !rhs || !x || !nreg) return fail("bad arguments");
+    for (int k = 0; k < nc; k++) if (map[k] < 0 || map[k] >= n || (k > 0 && map[k] <= map[k - 1])) return fail("srbm_debug_solve_mapped: the map must be increasing and within [0, n)");
+    const size_t np = (size_t)n * (n + 1) / 2, bytes = np * count * sizeof(double), vb = (size_t)n * count * sizeof(double);
+    double *dM = nullptr, *dr = nullptr, *dx = nullptr; int *dmap = nullptr, *dn = nullptr;
+    HIPCHK(hipMalloc(&dM, bytes)); HIPCHK(hipMalloc(&dr, vb)); HIPCHK(hipMalloc(&dx, vb)); HIPCHK(hipMalloc(&dmap, sizeof(int) * nc)); HIPCHK(hipMalloc(&dn, sizeof(int) * count));
+    HIPCHK(hipMemcpy(dM, M_packed, bytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dr, rhs, vb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dmap, map, sizeof(int) * nc, hipMemcpyHostToDevice));
+    const size_t lds = ((size_t)SRBM_NUMAX * (SRBM_NUMAX + 1) / 2 + DN_PANEL_DOUBLES + 3 * SRBM_NUMAX + (SRBM_NUMAX + 1) / 2) * sizeof(double);
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k_debug_solve_mapped), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(srbm_k_debug_solve_mapped, dim3(count), dim3(DN_THREADS), lds, 0, n, nc, dmap, dM, dr, dx, dn);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(x, dx, vb, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nreg, dn, sizeof(int) * count, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(dM)); HIPCHK(hipFree(dr)); HIPCHK(hipFree(dx)); HIPCHK(hipFree(dmap)); HIPCHK(hipFree(dn));
+    return 0;
+}
 /* unit-test hook: x = M^-1 rhs through Cholesky + explicit inverse of the factor; X_packed = L^-1; ticks[2*count] */
 int srbm_debug_solve(int n, int count, const double* M_packed, const double* rhs, double* x, double* X_packed, int* ticks) {
 #ifdef SRBM_LARGE

@@ -97,3 +97,35 @@ def test_explicit_factor_inverse_and_solve(n):
         assert np.abs(X @ L - np.eye(n)).max() <= 1e-10 * np.linalg.cond(L)
         xr = np.linalg.solve(M, b)
         assert np.abs(xv - xr).max() <= 1e-9 * max(1.0, np.abs(xr).max()) * np.linalg.cond(M) ** 0.5
+
+
+@pytest.mark.parametrize('n,nfix', [(20, 3), (120, 8), (120, 12), (120, 16), (137, 9), (148, 12), (160, 8), (160, 1), (33, 30)])
+def test_dense_phase_on_a_subset_of_the_columns(n, nfix):
+    """the IPM's dense phase leaves the pinned / substituted position variables (identity rows of the normal matrix) out: tiles loaded
+    through an increasing column map, factor and inverse of the free block, solves that gather and scatter through the map.  Against a
+    numpy solve of the FULL system with the identity rows in place; entries outside the map keep the right-hand side's value."""
+    lib = host.lib()
+    rng = np.random.default_rng(7000 + 31 * n + nfix)
+    fixed = np.sort(rng.choice(n, nfix, replace=False))
+    free = np.setdiff1d(np.arange(n), fixed).astype(np.int32)
+    mats, rhs = [], []
+    for _ in range(3):
+        G = rng.standard_normal((2 * n, n)); w = 10.0 ** rng.uniform(-3, 8, 2 * n)
+        M = 1e-2 * np.eye(n) + G.T @ (w[:, None] * G)
+        M[fixed, :] = 0; M[:, fixed] = 0; M[fixed, fixed] = 1.0
+        b = rng.standard_normal(n); b[fixed] = rng.standard_normal(nfix) * (rng.random(nfix) < 0.5)      # the IPM's are zero there; any value must survive
+        mats.append(M); rhs.append(b)
+    inp = np.ascontiguousarray(np.stack([pack(M) for M in mats])); r = np.ascontiguousarray(np.stack(rhs))
+    x = np.zeros_like(r); nreg = np.zeros(len(mats), np.int32)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)); ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    rc = lib.srbm_debug_solve_mapped(n, len(free), ip(free), len(mats), dp(inp), dp(r), dp(x), ip(nreg))
+    assert rc == 0, lib.srbm_last_error().decode()
+    assert np.all(nreg == 0)
+    for M, b, xv in zip(mats, rhs, x):
+        xr = np.linalg.solve(M, b)
+        assert np.array_equal(xv[fixed], b[fixed])
+        Mf = M[np.ix_(free, free)]
+        assert np.abs(xv - xr).max() <= 1e-9 * max(1.0, np.abs(xr).max()) * np.linalg.cond(Mf) ** 0.5
+    # a map that is not increasing is refused
+    bad = free.copy(); bad[[0, 1]] = bad[[1, 0]]
+    if len(bad) > 1: assert lib.srbm_debug_solve_mapped(n, len(bad), ip(bad), 1, dp(inp), dp(r), dp(x), ip(nreg)) != 0
