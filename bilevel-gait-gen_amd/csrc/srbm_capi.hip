@@ -367,6 +367,7 @@ __global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_solve(int n, const do
     chol_invert_diag_blocks(M, n);
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
     dn_trtri(M, n);
+    dn_scale_inverse_rows(M, n, panel);
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
     dn_solve_inv(0, n, (int)(xv - dbg_smem2), (int)(tv - dbg_smem2), -1, 0, 0
 #ifdef SRBM_M_GLOBAL
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_cholesky(int n, const
     dn_load_packed(T, M, n);
     dn_cholesky(T, M, n, panel, &nreg);
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
+    dn_scale_factor_columns(M, n, panel);         // (the test looks at L; dn_cholesky leaves L diag(sqrt(d)))
     for (int e = threadIdx.x; e < np; e += DN_THREADS) Lout[(size_t)blockIdx.x * np + e] = M[e];
     if (threadIdx.x == 0) nreg_out[blockIdx.x] = nreg | ((int)min((long long)0x7fffff, (t1 - t0) >> 4) << 8);   // bits 8..: ticks / 16 (diagnostic)
 }
@@ -418,6 +420,7 @@ __global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_solve_mapped(int n, i
     dn_cholesky(T, M, nc, panel, &nreg);
     chol_invert_diag_blocks(M, nc);
     dn_trtri(M, nc);
+    dn_scale_inverse_rows(M, nc, panel);
     dn_solve_inv(0, nc, (int)(xv - dbg_smem3), (int)(tv - dbg_smem3), (int)(reinterpret_cast<double*>(imap) - dbg_smem3), (int)(xc - dbg_smem3), 0
 #ifdef SRBM_M_GLOBAL
                  , M
