@@ -144,6 +144,7 @@ typedef struct SrbmWork {
     double Mg[SRBM_HPACK];                        /* SRBM_M_GLOBAL kernels: the normal matrix / its factor / the inverse of the factor of the IPM (in LDS otherwise) */
     double Ms[SRBM_HPACK];                        /* gait step: H + G' diag(lambda/s) G of the last solution (srbm_k3_normal_matrix) */
     double w0[SRBM_MIMAX];                        /* IPM: unit weight of the row/cost-scaled problem, e_r^2 / c (kernel 3 scratch) */
+    double hrow_g[SRBM_MIMAX];                    /* IPM: right-hand sides of the inequality rows (co-resident set: read from here instead of held in registers) */
     double prof2[64];                             /* diagnostic builds only: fine-grained stamps (K3_FINE) */
     double prof[16];                              /* diagnostic builds only (-DSRBM_PROFILE): cycles per IPM phase */
     double dbg[4 * 64];
