@@ -473,12 +473,48 @@ def main():
             t_qp += time.perf_counter() - ta
             bad_t += int((st_t != 0).sum()); bad_q += int((st_q > 1).sum()); qp_it.append(it_q.mean())
         el_w = max_over_ranks(time.perf_counter() - tw)
+        # ... and the same ticks with everything RESIDENT on the device: the device-pointer entries on the batch's own stream (torch only allocates
+        # and stacks the contact forces, on that stream), no copy and no synchronisation inside a tick -- what a batched controller would run
+        ext = torch.cuda.ExternalStream(mpc.stream())
+        with torch.cuda.stream(ext):
+            f64 = dict(dtype=torch.float64, device='cuda')
+            t_d = torch.zeros(nb, **f64); q_d = torch.tensor(q_des, **f64); v_d = torch.zeros((nb, 18), **f64); f_d = torch.zeros((nb, 4, 3), **f64)
+            st_d = torch.zeros(nb, dtype=torch.int32, device='cuda'); ef_d = torch.zeros((nb, 12), **f64); ep_d = torch.zeros((nb, 12), **f64)
+            con_d = torch.zeros((nb, 4), dtype=torch.int32, device='cuda'); ctl_d = torch.zeros((nb, 36), **f64); sol_d = torch.zeros((nb, 30), **f64)
+            stq_d = torch.zeros(nb, dtype=torch.int32, device='cuda')
+            gen = torch.Generator(device='cuda'); gen.manual_seed(4242 + lo)
+            bad_acc = torch.zeros(2, dtype=torch.int64, device='cuda')
+
+            def dev_tick(tk):
+                t_d.fill_(tk)
+                mpc.get_targets_from_traj_dev(t_d.data_ptr(), q_d.data_ptr(), v_d.data_ptr(), f_d.data_ptr(), st_d.data_ptr())
+                mpc.eval_trajectory_dev(t_d.data_ptr(), ef_d.data_ptr(), ep_d.data_ptr(), con_d.data_ptr())
+                order = torch.argsort((con_d == 0).to(torch.uint8), dim=1, stable=True)
+                fd_d = (torch.take_along_dim(f_d, order[:, :, None], dim=1) * (torch.take_along_dim(con_d, order, dim=1) > 0)[:, :, None]).reshape(nb, 12).contiguous()
+                qm_d = q_d.clone(); qm_d[:, 7:] += 0.01 * torch.randn((nb, 12), generator=gen, **f64)
+                vm_d = v_d + 0.01 * torch.randn((nb, 18), generator=gen, **f64)
+                mpc.qp_control_dev(qm_d.data_ptr(), vm_d.data_ptr(), con_d.data_ptr(), q_d.data_ptr(), v_d.data_ptr(), fd_d.data_ptr(), ctl_d.data_ptr(), sol_d.data_ptr(),
+                                   stq_d.data_ptr())
+                bad_acc[0] += (st_d != 0).sum(); bad_acc[1] += ((stq_d & 255) > 1).sum()
+                return fd_d, qm_d, vm_d                      # (kept alive until the stream has used them)
+
+            keep = dev_tick(t0w + 1e-3 * (args.wbc_ticks + 1))      # warm-up
+            mpc.synchronize(); bad_acc.zero_()
+            td0 = time.perf_counter()
+            for k in range(args.wbc_ticks): keep = dev_tick(t0w + 1e-3 * (args.wbc_ticks + 2 + k))
+            mpc.synchronize()
+            el_d = max_over_ranks(time.perf_counter() - td0)
+            bad_d = bad_acc.cpu().numpy(); ctl_fin = bool(torch.isfinite(ctl_d).all().item())
         wbc_stats = {'workload': '1 kHz control ticks downstream of the MPC for the %d instances of the batch: GetTargetsFromTraj (linear state interpolation, '
                                  'two IK solves, force splines) + QPControl::ComputeControlAction (dynamics by recursive Newton-Euler, whole-body QP), '
                                  'host-pointer entries (PCIe copies and the host-side stacking of the contact forces included)' % nb,
                      'ticks': args.wbc_ticks, 'control_actions_per_s': n_inst * args.wbc_ticks / el_w, 'ms_per_tick_of_the_batch': 1e3 * el_w / args.wbc_ticks,
                      'ms_per_tick_targets_only': 1e3 * t_targets / args.wbc_ticks, 'ms_per_tick_qp_control_only': 1e3 * t_qp / args.wbc_ticks,
-                     'targets_not_ok': bad_t, 'qp_not_solved': bad_q, 'mean_qp_ipm_iterations': float(np.mean(qp_it)), 'finite': bool(np.all(np.isfinite(ctl)))}
+                     'targets_not_ok': bad_t, 'qp_not_solved': bad_q, 'mean_qp_ipm_iterations': float(np.mean(qp_it)), 'finite': bool(np.all(np.isfinite(ctl))) and ctl_fin,
+                     'device_resident': {'note': 'the same ticks through the device-pointer entries on the batch\'s stream (srbm_get_targets_from_traj_dev, srbm_eval_trajectory_dev, '
+                                                 'srbm_qp_control_dev; contact forces stacked on the device): no copy, no synchronisation inside a tick',
+                                         'ms_per_tick_of_the_batch': 1e3 * el_d / args.wbc_ticks, 'control_actions_per_s': n_inst * args.wbc_ticks / el_d,
+                                         'targets_not_ok': int(bad_d[0]), 'qp_not_solved': int(bad_d[1])}}
     value = n_inst * args.steps / elapsed
 
     # quality of ALL timed solves of this rank (sticky accumulators), reduced over the ranks

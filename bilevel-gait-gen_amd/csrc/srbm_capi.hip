@@ -1558,6 +1558,15 @@ int srbm_eval_trajectory(srbm_batch* h, const double* time, double* force, doubl
     if (in_contact) memcpy(in_contact, o + 2 * nf, sizeof(int) * 4 * B);
     return 0;
 }
+int srbm_eval_trajectory_dev(srbm_batch* h, const double* time_dev, double* force_dev, double* pos_dev, int* in_contact_dev) {
+    if (!h || !time_dev || !force_dev || !pos_dev || !in_contact_dev) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    if (upload_params(h)) return -1;
+    const int tot = h->batch * SRBM_NEE;
+    hipLaunchKernelGGL(srbm_k_eval_trajectory, dim3((tot + 63) / 64), dim3(64), 0, h->stream, h->dp, h->insts, time_dev, force_dev, pos_dev, in_contact_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 int srbm_get_ee_box_center(const srbm_batch* h, double* centers) {
     if (!h || !centers) return fail("bad arguments");
     std::memcpy(centers, h->hp.hip, sizeof(double) * 8);

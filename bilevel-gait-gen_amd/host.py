@@ -430,6 +430,10 @@ class BatchMPC:
         """the same on device pointers (ints, e.g. torch tensors' data_ptr()): one launch on the batch's stream, no copy, no synchronisation"""
         self._chk(self.L.srbm_get_targets_from_traj_dev(self.h, C.c_void_p(time_ptr), C.c_void_p(q_des_ptr), C.c_void_p(v_des_ptr), C.c_void_p(force_des_ptr), C.c_void_p(status_ptr)))
 
+    def eval_trajectory_dev(self, time_ptr, force_ptr, pos_ptr, in_contact_ptr):
+        """Trajectory::GetForce / GetEndEffectorLocation / contact flags on device pointers (one launch, no copy)"""
+        self._chk(self.L.srbm_eval_trajectory_dev(self.h, C.c_void_p(time_ptr), C.c_void_p(force_ptr), C.c_void_p(pos_ptr), C.c_void_p(in_contact_ptr)))
+
     def qp_control_dev(self, q, v, contact, q_des, v_des, force_des, control, qp_sol, status):
         self._chk(self.L.srbm_qp_control_dev(self.h, *[C.c_void_p(p) for p in (q, v, contact, q_des, v_des, force_des, control, qp_sol, status)]))
 

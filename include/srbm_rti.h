@@ -156,6 +156,9 @@ int srbm_convert_tangent_to_manifold(const double* tangent12, double* state13);
 /* the same for the CURRENT trajectory of every instance on the device: time[batch] -> force[batch][4][3], pos[batch][4][3],
  * in_contact[batch][4] (any output may be NULL) */
 int srbm_eval_trajectory(srbm_batch* h, const double* time, double* force, double* pos, int* in_contact);
+/* ... the same on DEVICE pointers (one launch on the batch's stream, no copy, no synchronisation): the contact flags the whole-body QP of the
+ * same tick takes (srbm_qp_control_dev) without a round trip through the host; all four pointers required */
+int srbm_eval_trajectory_dev(srbm_batch* h, const double* time_dev, double* force_dev, double* pos_dev, int* in_contact_dev);
 /* MPCSingleRigidBody::GetEEBoxCenter (mpc/mpc_single_rigid_body.cpp:502-509): centers[4][2] = GetCOMToHip(ee).xy */
 int srbm_get_ee_box_center(const srbm_batch* h, double* centers);
 /* MPC::GetCost (cost of prev_qp_sol, cost[batch]) and MPC::GetAvgCost (mpc/mpc.cpp:991-998: mean over all solves so far) */

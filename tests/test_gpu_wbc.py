@@ -98,7 +98,7 @@ def test_full_batch_controller_properties():
 
 
 def test_device_pointer_entries_of_the_control_tick_equal_the_host_pointer_entries():
-    """srbm_get_targets_from_traj_dev / srbm_qp_control_dev: the same kernels on buffers that are already in HBM (hipMalloc'ed here through the HIP
+    """srbm_get_targets_from_traj_dev / srbm_eval_trajectory_dev / srbm_qp_control_dev: the same kernels on buffers that are already in HBM (hipMalloc'ed here through the HIP
     runtime), one launch each and no PCIe hop -- bit-identical to the host-pointer entries"""
     import ctypes as C
     hip = C.CDLL('libamdhip64.so')
@@ -131,6 +131,12 @@ def test_device_pointer_entries_of_the_control_tick_equal_the_host_pointer_entri
     g.get_targets_from_traj_dev(tt.p.value, tq.p.value, tv.p.value, tf.p.value, ts.p.value)
     g.synchronize()
     assert np.array_equal(tq.get(), qh) and np.array_equal(tv.get(), vh) and np.array_equal(tf.get().reshape(B, 4, 3), fh) and np.array_equal(ts.get(), sth)
+    # srbm_eval_trajectory_dev: forces, foot positions and the contact flags of the same instant, on device buffers
+    fe, pe, ce = g.eval_trajectory(t0)
+    ef, ep, ec = Dev(np.zeros((B, 12))), Dev(np.zeros((B, 12))), Dev(np.zeros((B, 4), np.int32))
+    g.eval_trajectory_dev(tt.p.value, ef.p.value, ep.p.value, ec.p.value)
+    g.synchronize()
+    assert np.array_equal(ef.get().reshape(fe.shape), fe) and np.array_equal(ep.get().reshape(pe.shape), pe) and np.array_equal(ec.get().reshape(ce.shape), ce)
     contact = np.array([CONTACTS[b % 3] for b in range(B)], np.int32)
     fdes = np.zeros((B, 12))
     for b in range(B):
