@@ -27,6 +27,19 @@ static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return -1; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
+// temporaries of the debug / export entries: released on every return path
+struct DevTemps {
+    std::vector<void*> ptrs;
+    ~DevTemps() { for (void* p : ptrs) (void)hipFree(p); }
+    template <class T> hipError_t alloc(T** out, size_t bytes) {
+        void* p = nullptr;
+        const hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = static_cast<T*>(p);
+        return e;
+    }
+};
+
 struct srbm_batch {
     int batch = 0, device = 0;
     SrbmParams hp{};                 // host copy of the parameters
@@ -52,6 +65,7 @@ struct srbm_batch {
     std::vector<int> ev_steps;        // RTI steps covered by each timed launch (1 for the stand-alone IPM kernel)
     size_t ev_used = 0;
     int gait_refs = 0;               // live srbm_gait handles borrowing this batch (and its stream)
+    double last_tol_step = 0.0;      // tol_step of the last solve launched on this batch: > 0 means its duals may not be at the gap tolerance
     SrbmWbcParams* d_wbc = nullptr;  // whole-body QP model and gains (row f3), set by srbm_set_wbc_model
     void* d_scratch = nullptr;       // staging buffer of the small host->device entry points (grown on demand, never per call)
     size_t scratch_bytes = 0;
@@ -169,7 +183,7 @@ __global__ void srbm_k_init(const SrbmParams* __restrict__ Pp, SrbmInst* __restr
     I.status = SRBM_UNSOLVED; I.qp_iters = 0; I.n = 0; I.m = 0; I.n_eq = 0; I.n_ineq = 0; I.nfv = 0; I.npv = 0; I.n_td = 0; I.n_samples = 0;
     I.err = 0; I.run_num = 0; I.acc_iters = 0; I.acc_flops = 0;
     I.cost_sum = 0; I.merit_dd = 0; I.acc_mfma = 0; I.err_acc = 0; I.n_solves = 0; I.n_not_solved = 0; I.n_maxiter = 0;
-    I.low_streak = 0; I.last_rule = 0; I.low_skip = 0; I.n_low_tried = 0; I.n_low_failed = 0; I.n_step_rule = 0;
+    I.low_streak = 0; I.last_rule = 0; I.last_low = 0; I.pad_low = 0; I.low_skip = 0; I.n_low_tried = 0; I.n_low_failed = 0; I.n_step_rule = 0;
 }
 
 __global__ void srbm_k_warm_start(const SrbmParams* __restrict__ Pp, SrbmInst* __restrict__ insts, const double* __restrict__ states) {
@@ -304,6 +318,7 @@ static int launch_step(srbm_batch* h, bool exact = false) {
     //  (Tried for the 10 x batch candidates of a gait line search, where dynamic workgroup scheduling evens out the tail: a candidate's linearisation
     //  point belongs to ANOTHER contact schedule -- 17-35 % of the attempts are repeated, the gait segment goes from 8.3 to 10.4-11.8 ms per step.)
     const double tol_step = exact ? 0.0 : h->hp.tol_step, start_mu = 0.0;
+    h->last_tol_step = tol_step;
     const int B = h->batch;
 #ifndef SRBM_LARGE
     if (h->kernel_set == 1) {
@@ -437,7 +452,8 @@ int srbm_debug_solve_mapped(int n, int nc, const int* map, int count, const doub
     for (int k = 0; k < nc; k++) if (map[k] < 0 || map[k] >= n || (k > 0 && map[k] <= map[k - 1])) return fail("srbm_debug_solve_mapped: the map must be increasing and within [0, n)");
     const size_t np = (size_t)n * (n + 1) / 2, bytes = np * count * sizeof(double), vb = (size_t)n * count * sizeof(double);
     double *dM = nullptr, *dr = nullptr, *dx = nullptr; int *dmap = nullptr, *dn = nullptr;
-    HIPCHK(hipMalloc(&dM, bytes)); HIPCHK(hipMalloc(&dr, vb)); HIPCHK(hipMalloc(&dx, vb)); HIPCHK(hipMalloc(&dmap, sizeof(int) * nc)); HIPCHK(hipMalloc(&dn, sizeof(int) * count));
+    DevTemps tmp;
+    HIPCHK(tmp.alloc(&dM, bytes)); HIPCHK(tmp.alloc(&dr, vb)); HIPCHK(tmp.alloc(&dx, vb)); HIPCHK(tmp.alloc(&dmap, sizeof(int) * nc)); HIPCHK(tmp.alloc(&dn, sizeof(int) * count));
     HIPCHK(hipMemcpy(dM, M_packed, bytes, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dr, rhs, vb, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dmap, map, sizeof(int) * nc, hipMemcpyHostToDevice));
@@ -448,7 +464,6 @@ int srbm_debug_solve_mapped(int n, int nc, const int* map, int count, const doub
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(x, dx, vb, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(nreg, dn, sizeof(int) * count, hipMemcpyDeviceToHost));
-    HIPCHK(hipFree(dM)); HIPCHK(hipFree(dr)); HIPCHK(hipFree(dx)); HIPCHK(hipFree(dmap)); HIPCHK(hipFree(dn));
     return 0;
 }
 /* unit-test hook: x = M^-1 rhs through Cholesky + explicit inverse of the factor; X_packed = L^-1; ticks[2*count] */
@@ -459,8 +474,9 @@ int srbm_debug_solve(int n, int count, const double* M_packed, const double* rhs
     if (n <= 0 || n > SRBM_NUMAX || count <= 0 || !M_packed || !rhs || !x || !X_packed || !ticks) return fail("bad arguments");
     const size_t np = (size_t)n * (n + 1) / 2, bytes = np * count * sizeof(double), vb = (size_t)n * count * sizeof(double);
     double *dM = nullptr, *dX = nullptr, *dr = nullptr, *dx = nullptr; int* dt = nullptr;
-    HIPCHK(hipMalloc(&dM, bytes)); HIPCHK(hipMalloc(&dX, bytes)); HIPCHK(hipMalloc(&dr, vb)); HIPCHK(hipMalloc(&dx, vb));
-    HIPCHK(hipMalloc(&dt, sizeof(int) * 2 * count));
+    DevTemps tmp;
+    HIPCHK(tmp.alloc(&dM, bytes)); HIPCHK(tmp.alloc(&dX, bytes)); HIPCHK(tmp.alloc(&dr, vb)); HIPCHK(tmp.alloc(&dx, vb));
+    HIPCHK(tmp.alloc(&dt, sizeof(int) * 2 * count));
     HIPCHK(hipMemcpy(dM, M_packed, bytes, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dr, rhs, vb, hipMemcpyHostToDevice));
     const size_t lds = ((size_t)SRBM_NUMAX * (SRBM_NUMAX + 1) / 2 + DN_PANEL_DOUBLES + 2 * SRBM_NUMAX) * sizeof(double);
@@ -471,7 +487,6 @@ int srbm_debug_solve(int n, int count, const double* M_packed, const double* rhs
     HIPCHK(hipMemcpy(x, dx, vb, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(X_packed, dX, bytes, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(ticks, dt, sizeof(int) * 2 * count, hipMemcpyDeviceToHost));
-    HIPCHK(hipFree(dM)); HIPCHK(hipFree(dX)); HIPCHK(hipFree(dr)); HIPCHK(hipFree(dx)); HIPCHK(hipFree(dt));
     return 0;
 }
 int srbm_debug_cholesky(int n, int count, const double* M_packed, double* L_packed, int* nreg) {
@@ -481,7 +496,8 @@ int srbm_debug_cholesky(int n, int count, const double* M_packed, double* L_pack
     if (n <= 0 || n > SRBM_NUMAX || count <= 0 || !M_packed || !L_packed || !nreg) return fail("bad arguments");
     const size_t np = (size_t)n * (n + 1) / 2, bytes = np * count * sizeof(double);
     double *dM = nullptr, *dL = nullptr; int* dr = nullptr;
-    HIPCHK(hipMalloc(&dM, bytes)); HIPCHK(hipMalloc(&dL, bytes)); HIPCHK(hipMalloc(&dr, sizeof(int) * count));
+    DevTemps tmp;
+    HIPCHK(tmp.alloc(&dM, bytes)); HIPCHK(tmp.alloc(&dL, bytes)); HIPCHK(tmp.alloc(&dr, sizeof(int) * count));
     HIPCHK(hipMemcpy(dM, M_packed, bytes, hipMemcpyHostToDevice));
     const size_t lds = ((size_t)SRBM_NUMAX * (SRBM_NUMAX + 1) / 2 + DN_PANEL_DOUBLES) * sizeof(double);
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k_debug_cholesky), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -490,7 +506,6 @@ int srbm_debug_cholesky(int n, int count, const double* M_packed, double* L_pack
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(L_packed, dL, bytes, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(nreg, dr, sizeof(int) * count, hipMemcpyDeviceToHost));
-    HIPCHK(hipFree(dM)); HIPCHK(hipFree(dL)); HIPCHK(hipFree(dr));
     return 0;
 }
 int srbm_debug_get_trace(srbm_batch* h, int inst, double* out256) {
@@ -548,7 +563,9 @@ static int alloc_batch(srbm_batch* h, hipStream_t borrowed_stream) {
         int n_cu = 0;
         HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
         h->n_cu = n_cu;
-        h->co_available = srbm_co_configure(h->hp.N, &h->k3_lds_co) == 0;
+        const int co_rc = srbm_co_configure(h->hp.N, &h->k3_lds_co);     // 0 ok, -2 this horizon does not fit half a CU (stay on set 0), -1 a HIP error
+        if (co_rc == -1) return fail(std::string("srbm_co_configure: ") + hipGetErrorString(hipGetLastError()));
+        h->co_available = co_rc == 0;
         if (h->co_available) HIPCHK(hipMalloc(&h->dp_co, sizeof(SrbmParams)));
         h->kernel_set = (h->co_available && n_cu > 0 && h->batch > n_cu) ? 1 : 0;
     }
@@ -588,7 +605,7 @@ int srbm_batch_create(srbm_batch** out, int batch, const srbm_mpc_info* info, co
     // 1024 solves) the worst relative primal error is 1.3e-4 at 1e-13, 5e-5 at 1e-14 and 1.4e-5 at 1e-15, for 17.3 / 18.0 /
     // 18.9 IPM iterations per solve.  The parity tolerance of the path is 1e-4.  srbm_set_solver_tolerances overrides.
     p.tol_gap_abs = 1e-15; p.tol_gap_rel = 1e-15; p.tol_feas = 1e-10;
-    p.tol_step = SRBM_DEFAULT_TOL_STEP; p.start_mu = SRBM_DEFAULT_START_MU;      // srbm_set_solver_step_rule
+    p.tol_step = 0.0; p.start_mu = 0.0;       // the reference's criterion; srbm_set_solver_step_rule opts into the faster termination
     auto bail = [&]() { free_batch(h); return -1; };
     if (alloc_batch(h, nullptr)) return bail();
     if (hipMemsetAsync(h->works, 0, sizeof(SrbmWork) * (size_t)batch, h->stream) != hipSuccess) { fail("srbm_batch_create: memset failed"); return bail(); }
@@ -605,7 +622,7 @@ int srbm_batch_clone(const srbm_batch* src, srbm_batch** out) {
     HIPCHK(hipSetDevice(src->device));
     HIPCHK(hipStreamSynchronize(src->stream));
     auto* h = new srbm_batch;
-    h->batch = src->batch; h->device = src->device; h->hp = src->hp; h->push_set = src->push_set;
+    h->batch = src->batch; h->device = src->device; h->hp = src->hp; h->push_set = src->push_set; h->last_tol_step = src->last_tol_step;
     auto bail = [&]() { free_batch(h); return -1; };
     if (alloc_batch(h, nullptr)) return bail();
     h->kernel_set = src->kernel_set;
@@ -741,10 +758,11 @@ int srbm_get_real_time_update_dev(srbm_batch* h, const double* state_dev, const 
 static int launch_fused(srbm_batch* h, int first_index, int steps, SrbmPlantArgs pl) {
     // (the lower-start attempt rests on the linearisation point being close to the new minimiser: true for the open-loop protocol, whose state IS
     //  node 1 of the plan; under a plant -- integration error every step, pushes -- it is repeated too often to pay: closed loop 62 k it/s with, 80 k without)
-    pl.tol_step = h->hp.tol_step; pl.start_mu = pl.plant ? 0.0 : h->hp.start_mu;
+    pl.tol_step = h->hp.tol_step; pl.start_mu = (pl.plant || pl.tol_step <= 0.0) ? 0.0 : h->hp.start_mu;
     HIPCHK(hipSetDevice(h->device));
     if (upload_params(h)) return -1;
     if (steps == 0) return 0;
+    h->last_tol_step = pl.tol_step;
     // one launch for all steps (double time = i*info.integrator_dt, gait_opt_playground.cpp:84, is formed on the device)
     const bool tm = h->timing && h->ev_used < h->ev_start.size();
     if (tm) HIPCHK(hipEventRecord(h->ev_start[h->ev_used], h->stream));
@@ -973,6 +991,10 @@ int srbm_gait_get_step(srbm_gait* g, double* step) {
 int srbm_gait_compute_sensitivity(srbm_gait* g) {
     if (!g) return fail("bad arguments");
     srbm_batch* h = g->h;
+    if (h->last_tol_step > 0.0)
+        return fail("srbm_gait_compute_sensitivity: the last solve of this batch ran with the step rule (tol_step > 0): its multipliers are not at the "
+                    "gap tolerance the KKT sensitivity needs -- call srbm_set_solver_step_rule(h, 0, start_mu) before the solve that is differentiated "
+                    "(srbm_gait_rti_advance does so by itself)");
     HIPCHK(hipSetDevice(h->device));
     if (upload_params(h)) return -1;
     hipLaunchKernelGGL(srbm_k3_normal_matrix, dim3(h->batch), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works);
@@ -1006,22 +1028,23 @@ int srbm_gait_get_param_partials(srbm_batch* h, int inst, int ee, int idx, doubl
     if (n == 0 || me == 0) return fail("srbm_gait_get_param_partials: no QP has been solved yet");
     double* d = nullptr;
     const size_t tot = me * n + mi * n + me + 1;
-    HIPCHK(hipMalloc(&d, sizeof(double) * tot));
-    int rc = 0;
-    auto done = [&](int r) { (void)hipFree(d); return r; };
-    if (hipMemsetAsync(d, 0, sizeof(double) * tot, h->stream) != hipSuccess) return done(fail("memset failed"));
+    DevTemps tmp;
+    HIPCHK(tmp.alloc(&d, sizeof(double) * tot));
+    HIPCHK(hipMemsetAsync(d, 0, sizeof(double) * tot, h->stream));
     int* derr = reinterpret_cast<int*>(d + me * n + mi * n + me);
     hipLaunchKernelGGL(srbm_k_gait_param_partials, dim3(1), dim3(KH_THREADS), 0, h->stream, h->dp, h->insts + inst, h->works + inst, ee, idx,
                        d, d + me * n, d + me * n + mi * n, derr);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return done(fail("srbm_gait_get_param_partials: kernel failed"));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
     int err = 0;
-    if (hipMemcpy(dA, d, sizeof(double) * me * n, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(dG, d + me * n, sizeof(double) * mi * n, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(db, d + me * n + mi * n, sizeof(double) * me, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&err, derr, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
-        return done(fail("srbm_gait_get_param_partials: copy failed"));
+    HIPCHK(hipMemcpy(dA, d, sizeof(double) * me * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dG, d + me * n, sizeof(double) * mi * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(db, d + me * n + mi * n, sizeof(double) * me, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&err, derr, sizeof(int), hipMemcpyDeviceToHost));
     std::memset(dh, 0, sizeof(double) * mi);
-    if (err & SRBM_ERR_CAPACITY) return done(fail("srbm_gait_get_param_partials: contact index out of range"));
-    if (err) return done(fail("srbm_gait_get_param_partials: spline lookup failed (error bits " + std::to_string(err) + ")"));
-    return done(rc);
+    if (err & SRBM_ERR_CAPACITY) return fail("srbm_gait_get_param_partials: contact index out of range");
+    if (err) return fail("srbm_gait_get_param_partials: spline lookup failed (error bits " + std::to_string(err) + ")");
+    return 0;
 }
 int srbm_gait_get_gradient(srbm_gait* g, double* dHdth, int* valid) {
     if (!g || !dHdth) return fail("bad arguments");
@@ -1622,6 +1645,13 @@ int srbm_get_solver_counters(srbm_batch* h, long long* c4) {
     if (fetch_insts(h, v)) return -1;
     c4[0] = c4[1] = c4[2] = c4[3] = 0;
     for (auto& I : v) { c4[0] += I.n_solves; c4[1] += I.n_step_rule; c4[2] += I.n_low_tried; c4[3] += I.n_low_failed; }
+    return 0;
+}
+int srbm_get_solve_flags(srbm_batch* h, int* flags) {
+    if (!h || !flags) return fail("bad arguments");
+    std::vector<SrbmInst> v;
+    if (fetch_insts(h, v)) return -1;
+    for (int b = 0; b < h->batch; b++) flags[b] = (v[b].last_rule ? 1 : 0) | ((v[b].last_low & 1) ? 2 : 0) | ((v[b].last_low & 2) ? 4 : 0);
     return 0;
 }
 int srbm_result_record_doubles(int N) { return 8 + 12 * (N + 1) + SRBM_NUMAX + 12 * (N + 1) + 6 * SRBM_NSMAX + 16 * (N - 3) + 16 + 36; }

@@ -62,7 +62,9 @@ typedef struct SrbmParams {
     double tol_gap_abs, tol_gap_rel, tol_feas;
     /* (host-side record of srbm_set_solver_step_rule; the kernels receive the two values as launch arguments)  tol_step > 0 ends a solve as soon as the affine (predictor) Newton step -- the distance to the KKT point of
        the QP as the factor at hand sees it -- is below tol_step * max(1, |u|_inf): the iterate then takes that step and the solve is over;
-       start_mu > 0: every solve is first attempted from Clarabel's starting point with the multipliers scaled to mean(s o lambda) = start_mu */
+       start_mu > 0 (fused open-loop launches only): every solve is first attempted from the LINEARISATION POINT with slacks h - G u and centred
+       multipliers lambda = start_mu / s (K3_LOW_MODE 1, the compiled default; mode 0 = Clarabel's point with scaled multipliers is an A/B switch).
+       Both are 0 in a new batch: the reference's gap criterion (include/srbm_rti.h, srbm_set_solver_step_rule) */
     double tol_step, start_mu;
     double legs[SRBM_NEE][4][3];    /* leg geometry for the IK of row f3 (srbm_ik.hiph): joint origins hip / thigh / calf / foot */
     int has_legs, pad2;
@@ -89,6 +91,7 @@ typedef struct SrbmInst {
     int err_acc, n_solves, n_not_solved, n_maxiter;       /* n_not_solved: status not in {Solved, SolvedInacc}; n_maxiter: of those, MaxIter */
     int low_streak, last_rule;                            /* last_rule: 1 if the LAST solve ended through the step rule (its duals are then not at the reference's gap tolerance: the
                                                              gait gradient is marked invalid); low_streak: consecutive failed attempts: the back-off doubles with each (K3_LOW_BACKOFF << streak, at most 48 solves) */
+    int last_low, pad_low;                                /* last solve: bit 0 began with a lower-start attempt, bit 1 the attempt was repeated from the standard start */
     int low_skip, n_low_tried, n_low_failed, n_step_rule; /* lower-start attempts (srbm_k3_ipm.hiph): solves left that skip the attempt, attempts, attempts repeated
                                                              from the standard start; solves ended by the step rule */
 } SrbmInst;

@@ -43,6 +43,9 @@ class Model(C.Structure):            # srbm_model
 
 
 KMAX, NODES_MAX = 32, 101
+# srbm_set_solver_step_rule: a new batch runs every solve to the reference's gap criterion (0, 0); these are the values bench.py opts into for
+# its headline line (include/srbm_rti.h: SRBM_FAST_TOL_STEP, SRBM_FAST_START_MU)
+FAST_TOL_STEP, FAST_START_MU = 1e-5, 0.1
 
 
 class Trajectory(C.Structure):       # srbm_trajectory: mpc::Trajectory as a flat record (include/srbm_rti.h)
@@ -85,9 +88,16 @@ class Trajectory(C.Structure):       # srbm_trajectory: mpc::Trajectory as a fla
 
 
 def build(force=False):
-    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
-    if force or not os.path.exists(LIB_PATH):
-        subprocess.check_call(['make', '-s', '-C', os.path.join(HERE, 'csrc')])
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU).  Serialised by a file lock: the ranks of a multi-GPU run that
+    find a library missing (a fresh box) must not run `make` on the same tree at the same time."""
+    if force or not (os.path.exists(LIB_PATH) and os.path.exists(LIB_PATH_LARGE)):
+        import fcntl
+        with open(os.path.join(HERE, 'csrc', '.build.lock'), 'w') as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            try:
+                subprocess.check_call(['make', '-s', '-j3', '-C', os.path.join(HERE, 'csrc')])
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
     return LIB_PATH
 
 
@@ -327,6 +337,16 @@ class BatchMPC:
 
     def set_solver_step_rule(self, tol_step, start_mu=0.0):
         self._chk(self.L.srbm_set_solver_step_rule(self.h, C.c_double(tol_step), C.c_double(start_mu)))
+
+    def enable_fast_termination(self, start_mu=FAST_START_MU):
+        """opt into the step rule (and, for srbm_rti_advance, the lower-start attempt) at the values the bench line is taken with"""
+        self.set_solver_step_rule(FAST_TOL_STEP, start_mu)
+
+    def solve_flags(self):
+        """per instance, of the LAST solve: bit 0 ended through the step rule, bit 1 began with a lower-start attempt, bit 2 the attempt was repeated"""
+        f = np.zeros(self.batch, np.int32)
+        self._chk(self.L.srbm_get_solve_flags(self.h, _i(f)))
+        return f
 
     def set_kernel_set(self, which):
         """0: one instance per CU (512 threads, M in LDS); 1: two instances per CU (256 threads, M in L2) -- the default follows the batch size"""

@@ -60,23 +60,32 @@ int srbm_set_state_trajectory_warm_start(srbm_batch* h, const double* states);
 /* ClarabelInterface tolerances (mpc/qp/clarabel_interface.cpp:18-27,165-175) for the on-device IPM.
  * Defaults: the reference's own -- gap 1e-15, feasibility 1e-10 -- and 200 iterations (Clarabel's max_iter) */
 int srbm_set_solver_tolerances(srbm_batch* h, double tol_gap_abs, double tol_gap_rel, double tol_feas, int max_iter);
-/* Two settings of the on-device solver that have no counterpart in ClarabelInterface (mpc/qp/clarabel_interface.cpp:72-155 runs Clarabel to
- * its 1e-15 gap).  tol_step > 0: a solve ALSO ends Solved as soon as the affine Newton step -- which measures the distance of the iterate to the
- * minimiser of the QP -- is below tol_step * max(1, |u|_inf); the iterate then takes that step (what is left is <= 0.2 tol_step).  start_mu > 0:
- * every solve is first attempted from the linearisation point (the shifted solution of the previous RTI step) with slacks h - G u and perfectly
- * centred multipliers lambda = start_mu / s -- five to six decades further down the central path than Clarabel's starting point -- and repeated from the
- * standard point unless the attempt ends through the step rule (the device-resident open-loop launch srbm_rti_advance only: there a repeated
- * attempt of one instance is averaged over its K steps -- a one-step launch would wait for it every time -- and the state is node 1 of the plan).  Both 0: exactly the gap
- * criterion of srbm_set_solver_tolerances.
- * The bilevel step differentiates the KKT system of a solve and needs its duals at the reference's tolerance: srbm_gait_rti_advance runs that
- * one solve of its protocol at the gap criterion by itself; a caller that drives the protocol (srbm_get_real_time_update, then
- * srbm_gait_compute_gradient) switches the rule off for the batch -- the gradient of a solve that ended through the step rule is marked
- * invalid (valid[b] = 0, as for a QP that is not Solved).
- * Defaults: SRBM_DEFAULT_TOL_STEP, SRBM_DEFAULT_START_MU (1e-4 relative primal accuracy is the bar of the path). */
-#define SRBM_DEFAULT_TOL_STEP 1e-5
-#define SRBM_DEFAULT_START_MU 0.1
+/* Two OPT-IN settings of the on-device solver that have no counterpart in ClarabelInterface (mpc/qp/clarabel_interface.cpp:72-155 runs Clarabel
+ * to its 1e-15 gap).  A new batch has both at 0: every solve then ends by exactly the gap criterion of srbm_set_solver_tolerances, i.e. the
+ * reference's (clarabel_interface.cpp:165-175), its multipliers are at that tolerance and any solve may be differentiated afterwards.
+ *   tol_step > 0: a solve ALSO ends Solved as soon as the affine Newton step -- which measures the distance of the iterate to the minimiser of
+ *     the QP -- is below tol_step * max(1, |u|_inf); the iterate then takes that step (what is left is <= 0.2 tol_step).  Applies to EVERY
+ *     launch path (srbm_get_real_time_update[_dev], srbm_rti_advance[_unfused], srbm_closed_loop_advance, the line-search candidates and the
+ *     plain RTI steps of srbm_gait_rti_advance).  The primal point is then accurate to tol_step, the multipliers only to that order: a solve
+ *     that ended through the rule is flagged (srbm_get_solve_flags bit 0), residuals / gap / QP cost reported for it are re-evaluated at the
+ *     returned iterate, and srbm_gait_compute_sensitivity / _gradient REFUSE it (error return, not a silent valid = 0) -- srbm_gait_rti_advance
+ *     runs the one solve it differentiates at the gap criterion by itself, a caller that drives that protocol passes tol_step = 0 first.
+ *   start_mu > 0 (needs tol_step > 0): every solve is first ATTEMPTED from the linearisation point (the shifted solution of the previous RTI
+ *     step) with slacks h - G u and perfectly centred multipliers lambda = start_mu / s -- five to six decades further down the central path
+ *     than Clarabel's starting point -- and repeated from the standard point unless the attempt ends through the step rule.  Honoured by the
+ *     device-resident open-loop launch srbm_rti_advance ONLY (there a repeated attempt of one instance is averaged over its K steps and the
+ *     state is node 1 of the plan); IGNORED by srbm_get_real_time_update[_dev], srbm_rti_advance_unfused, srbm_create_initial_run (one-step
+ *     launches wait for the slowest instance every time), by srbm_closed_loop_advance (integration error and pushes make the attempts fail)
+ *     and by srbm_gait_rti_advance (its candidates belong to other contact schedules).
+ * SRBM_FAST_TOL_STEP / SRBM_FAST_START_MU are the values bench.py opts into for its headline line (1e-4 relative primal accuracy is the bar of
+ * the path; parity of that mode: tests/test_gpu_resync.py); the same line carries the run at (0, 0). */
+#define SRBM_FAST_TOL_STEP 1e-5
+#define SRBM_FAST_START_MU 0.1
 int srbm_set_solver_step_rule(srbm_batch* h, double tol_step, double start_mu);
 int srbm_get_solver_step_rule(const srbm_batch* h, double* tol_step, double* start_mu);
+/* flags[batch] of the LAST solve: bit 0 = ended through the step rule (duals not at the gap tolerance), bit 1 = began with a lower-start attempt,
+ * bit 2 = that attempt was repeated from the standard starting point */
+int srbm_get_solve_flags(srbm_batch* h, int* flags);
 /* The library carries the kernels of the RTI path twice (same sources): set 0, one instance per CU (512 threads, the normal matrix of the solve in
  * LDS) and set 1, two instances per CU (256 threads, <= 80 KB of LDS, the normal matrix in L2).  A batch with more instances than the GPU has
  * CUs is created on set 1 -- the instances then fill each other's latency gaps -- every other batch on set 0; srbm_set_kernel_set overrides

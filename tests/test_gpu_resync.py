@@ -33,13 +33,14 @@ def cls(v):
     return 'solved' if v <= 1 else ('maxiter' if v == 2 else ('infeasible' if v in (3, 5) else 'other'))
 
 
-def make_batch(cfg, states, ees, step_rule=True):
+def make_batch(cfg, states, ees, step_rule=True, large=None):
     B = len(states)
-    g = host.BatchMPC(cfg, B)
+    g = host.BatchMPC(cfg, B, large=large)
     g.set_state_trajectory_warm_start(states)
     g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
-    if not step_rule:
-        g.set_solver_step_rule(0.0, 0.0)        # exactly the reference's criterion (gap 1e-15): include/srbm_rti.h
+    assert g.solver_step_rule() == (0.0, 0.0)   # a new batch: exactly the reference's criterion (gap 1e-15), include/srbm_rti.h
+    if step_rule:
+        g.enable_fast_termination()             # the mode bench.py times: tol_step 1e-5, start_mu 0.1 (the latter acts in srbm_rti_advance only)
     oracles = []
     for b in range(B):
         o = OracleMPC(cfg)
@@ -48,16 +49,20 @@ def make_batch(cfg, states, ees, step_rule=True):
     return g, oracles
 
 
-def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None, step_rule=True, min_alive=None):
+def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None, step_rule=True, min_alive=None, fused=False, large=None):
     """cold start on both sides, then `steps` open-loop RTI steps (test/gait_opt_playground.cpp:113-126) with the device
-    re-synchronised to the oracle before every step; returns per-step statistics.  Asserts entry-wise parity."""
+    re-synchronised to the oracle before every step; returns per-step statistics.  Asserts entry-wise parity.
+    fused=False: the device steps through srbm_get_real_time_update (host-pointer entry, one launch per phase: the lower-start attempt is
+    never made there).  fused=True: through srbm_rti_advance(i, 1) -- the device-resident launch bench.py times, which takes node 1 and the
+    spline feet of the installed trajectory as its inputs and, with start_mu > 0, begins every solve with the lower-start ATTEMPT."""
     B = len(states)
     N = cfg['num_nodes']
     dt = cfg['integrator_dt']
-    g, oracles = make_batch(cfg, states, ees, step_rule)
+    g, oracles = make_batch(cfg, states, ees, step_rule, large)
     pool = pool or ThreadPoolExecutor(16)
     list(pool.map(lambda b: oracles[b].initial_run(states[b], ees[b].reshape(4, 3)), range(B)))
     g.create_initial_run(states, ees.reshape(B, 12))
+    g.clear_status_accumulators()              # (the counters below describe the re-synchronised steps only)
     # after the cold start (10 solves, each side on its own path) the two sides agree to the tolerance ...
     xs = g.qp_solution()
     st0, _ = g.status()
@@ -84,10 +89,17 @@ def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None, step_rule=Tr
         assert bytes(back) == bytes(recs)                      # the record round-trips bit for bit
         own_states = g.trajectory_states()
         _, own_ee, _ = g.eval_trajectory(t)
-        st_in = np.array([(o.states()[1] if i > 0 else states[b]) if alive[b] else own_states[b, 1] for b, o in enumerate(oracles)])
+        # (fused: the launch reads node 1 of the installed trajectory at every step, the first included -- the oracle is given the same)
+        st_in = np.array([(o.states()[1] if (i > 0 or fused) else states[b]) if alive[b] else own_states[b, 1] for b, o in enumerate(oracles)])
         ee_in = np.array([[[o.ee_value(e, 1, c, t) for c in range(3)] for e in range(4)] if alive[b] else own_ee[b]
                           for b, o in enumerate(oracles)]).reshape(B, 12)
-        g.get_real_time_update(st_in, t, ee_in)
+        if fused:
+            g.rti_advance(i, 1); g.synchronize()
+            if step_rule:       # every solve of this launch began with an attempt (installing a trajectory resets the back-off)
+                fl = g.solve_flags()
+                assert np.all(fl & 2), (i, np.nonzero((fl & 2) == 0)[0][:8])
+        else:
+            g.get_real_time_update(st_in, t, ee_in)
         sos = list(pool.map(lambda b: oracles[b].rti(st_in[b], t, ee_in[b].reshape(4, 3)) if alive[b] else 8, range(B)))
         sz = g.sizes(); st, err = g.status(); stats = g.stats()
         x = g.qp_solution(); xr = g.raw_qp_minimiser(); z, s = g.dual_solution(); tr = g.trajectory_states()
@@ -203,7 +215,11 @@ def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None, step_rule=Tr
             if alive[b]:
                 assert np.array_equal(g.knots(b)['box'], np.array(oracles[b].stats()['box'])), (i, b)
     assert alive.sum() >= (0.97 * B if min_alive is None else min_alive), alive.sum()
-    return dict(alive=int(alive.sum()), sizes=seen_sizes, td_steps=seen_td, worst=worst, exact_status=exact_status, total=total, z_unique=n_unique, certified=n_cert)
+    ctr = g.solver_counters()
+    assert ctr['solves'] == B * steps
+    if fused and step_rule:                    # the test cannot silently run without attempts
+        assert ctr['low_tried'] >= 0.8 * ctr['solves'], ctr
+    return dict(counters=ctr, alive=int(alive.sum()), sizes=seen_sizes, td_steps=seen_td, worst=worst, exact_status=exact_status, total=total, z_unique=n_unique, certified=n_cert)
 
 
 def test_config_b_all_256_instances_entrywise_over_20_steps():
@@ -219,6 +235,50 @@ def test_config_b_all_256_instances_entrywise_over_20_steps():
     print('resync parity, 256 x 20: alive', r['alive'], 'worst', r['worst'], 'exact status matches %d / %d' % (r['exact_status'], r['total']),
           'duals compared entry-wise (unique multipliers) in %d solves' % r['z_unique'], 'certified minimisers: %d' % r['certified'])
     assert r['certified'] >= 40
+
+
+def test_config_b_all_256_through_the_fused_launch_with_lower_start_attempts():
+    """THE MODE bench.py TIMES: all 256 Config-B instances over 20 steps through srbm_rti_advance(i, 1) with tol_step 1e-5 and
+    start_mu 0.1 -- every solve begins with the lower-start attempt, ends by the step rule or is repeated from the standard start -- entry-wise
+    against the oracle (Clarabel restatement at gap 1e-15) on identical QPs, same bounds as the host-pointer protocol above"""
+    cfg = load_config()
+    B = 256
+    states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees)
+    r = resync_protocol(cfg, states, ees, steps=20, min_alive=255, fused=True)
+    nx = 21 * 12
+    assert {nx + 120, nx + 148} <= r['sizes'], r['sizes']
+    assert r['td_steps'] > 0
+    assert r['worst']['A'] <= 1e-12 and r['worst']['x'] < REL_TOL and r['worst']['z'] < REL_TOL and r['worst']['states'] < REL_TOL
+    c = r['counters']
+    print('resync parity THROUGH THE FUSED LAUNCH, 256 x 20, tol_step 1e-5 / start_mu 0.1: alive', r['alive'], 'worst', r['worst'],
+          'solves %d, ended by the step rule %d, began with an attempt %d, attempts repeated %d' % (c['solves'], c['step_rule'], c['low_tried'], c['low_failed']),
+          'certified minimisers: %d' % r['certified'])
+    assert c['low_tried'] == c['solves'] and c['step_rule'] >= 0.9 * c['solves']
+    assert r['certified'] >= 40
+
+
+def test_config_d_share_through_the_fused_launch_with_lower_start_attempts():
+    """... the Config-D share (N = 50, dt = 0.02, pushed initial momenta; the 3-rows-per-thread instance of the kernel): 16 instances x 6 steps"""
+    cfg = load_config('a1_config_distr_rejection')
+    B = 16
+    states, ees = zip(*[config_d_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees)
+    r = resync_protocol(cfg, states, ees, steps=6, qp_every=2, fused=True)
+    assert r['worst']['A'] <= 1e-12 and r['worst']['x'] < REL_TOL
+    print('resync parity through the fused launch, config D 16 x 6: alive', r['alive'], 'worst', r['worst'], r['counters'])
+
+
+def test_n40_share_through_the_fused_launch_with_lower_start_attempts():
+    """... and the N = 40 share (Config E, LARGE-capacity build: normal matrix in L2, up to 232 spline variables): 8 instances x 5 steps"""
+    cfg = load_config(num_nodes=40)
+    B = 8
+    states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees)
+    r = resync_protocol(cfg, states, ees, steps=5, qp_every=2, fused=True, large=True)
+    assert r['worst']['A'] <= 1e-12 and r['worst']['x'] < REL_TOL
+    assert max(r['sizes']) - 41 * 12 > 160                   # beyond the standard build's capacity
+    print('resync parity through the fused launch, N = 40 (LARGE build) 8 x 5: alive', r['alive'], 'worst', r['worst'], r['counters'])
 
 
 def test_config_b_at_the_reference_criterion_entrywise():
