@@ -210,6 +210,10 @@ def free_port():
 def spawn_ranks(args):
     """`python bench.py --gpus N` (N > 1) outside torchrun: start N fresh rank processes of this same script.  The parent has not
     imported torch and never touches a GPU; nothing is exec'd from a GPU-initialised process."""
+    # the ranks would otherwise race on `make` when a library is missing (fresh box): build once, here (make only -- the parent never touches a GPU)
+    if not args.dry_run:
+        from srbm_loader import host
+        host.build()
     port = free_port()
     procs = []
     for r in range(args.gpus):
@@ -256,6 +260,11 @@ def main():
                     help='extra, separately timed segment (Config C): controller loop with the bilevel (gait) step every 5th iteration (0 = skip)')
     ap.add_argument('--wbc-ticks', type=int, default=20,
                     help='fourth segment: 1 kHz control ticks (targets from the trajectory by IK + whole-body QP) of the batch; 0 skips it')
+    ap.add_argument('--no-reference-criterion', action='store_true', help='skip the second run of the Config-B protocol at the reference\'s gap criterion')
+    ap.add_argument('--reference-criterion-only', action='store_true', help='the headline itself at the reference\'s criterion (no step rule, no lower start)')
+    ap.add_argument('--extra-workloads', type=int, default=1, help='1 (default): short Config D and Config E runs quoted as config_d / config_e objects (workload B only)')
+    ap.add_argument('--n1-baseline', type=float, default=float(os.environ.get('SRBM_BENCH_N1_BASELINE', '0') or 0),
+                    help='it/s of the 1-GPU run of the same command: the line then carries weak_scaling_efficiency = value / (n_gpus * this)')
     ap.add_argument('--dry-run', action='store_true', help='CPU rehearsal of the launcher / sharding / gather path (gloo, no HIP call)')
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.repeats < 1:
@@ -299,7 +308,9 @@ def main():
         if rank == 0:
             print(json.dumps({'metric': 'MPC RTI iterations/sec (batched A1 SRBM, N=%d)' % cfg['num_nodes'], 'value': 0.0, 'unit': 'it/s',
                               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'dry_run': True, 'scaling': 'weak',
-                              'config': {'batch_per_gpu': B, 'global_batch': n_inst, 'records_gathered': int(allrec.shape[0]), 'gather_ok': ok}}))
+                              'collective_world_size': dist.get_world_size() if world > 1 else 1,
+                              'config': {'batch_per_gpu': B, 'global_batch': n_inst, 'records_gathered': int(allrec.shape[0]), 'gather_ok': ok,
+                                         'shard_bounds': [list(shard_range(n_inst, r_, world)) for r_ in range(world)]}}))
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -317,56 +328,112 @@ def main():
             os.environ['MASTER_PORT'] = str(free_port())      # (one-rank rehearsal: no peer needs to know it)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
-    states, ees = zip(*[make_instance(cfg, b) for b in range(lo, hi)])
-    states, ees = np.array(states), np.array(ees).reshape(hi - lo, 12)
-
-    mpc = host.BatchMPC(cfg, hi - lo, device=local_rank, large=(args.workload == 'E'))     # a 2 s horizon needs 232 spline variables: LARGE build
-    mpc.set_state_trajectory_warm_start(states)
-    mpc.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
-    mpc.create_initial_run(states, ees)                       # 10 cold-start solves (set-up, untimed)
-    mpc.rti_advance(0, args.warmup)
-    mpc.synchronize()
-    LD = mpc.result_record_doubles()                          # status..., primal, dual, contact times (SURVEY.md 8e record)
-    rec = torch.zeros((hi - lo, LD), dtype=torch.float64, device='cuda')
-    if DIST:                                             # first collective outside the timed region (communicator set-up)
-        gather_records(rec, world)
-        torch.cuda.synchronize()
-
-    mpc.clear_status_accumulators()
-    it0, fl0 = mpc.work_counters()
-    mf0 = mpc.executed_mfma()
-    mpc.enable_kernel_timing(args.repeats + 2)     # every timed region is ONE launch of the fused RTI kernel
-    region_s = []
-    region_work = []                          # (IPM iterations, algorithmic flops, executed MFMA) of each region's launch
-    first = args.warmup
-    allrec = None
-    prev_ctr = (it0, fl0, mf0)
-    for rep in range(args.repeats):
+    def solved_quality(acc):
+        """[error bits, solves, not solved, max-iter] of ALL timed solves (sticky accumulators), reduced over the ranks"""
+        q = np.array([float(np.bitwise_or.reduce(acc[:, 0])), float(acc[:, 1].sum()), float(acc[:, 2].sum()), float(acc[:, 3].sum())])
         if DIST:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        mpc.rti_advance(first, args.steps)                    # K device-resident RTI steps
-        mpc.pack_results_dev(rec.data_ptr(), LD)
-        mpc.synchronize()
-        allrec = gather_records(rec, world)                   # RCCL all-gather of the solved trajectories (primal + dual + schedule)
-        torch.cuda.synchronize()
-        if DIST:
-            dist.barrier()
-        region_s.append(max_over_ranks(time.perf_counter() - t0))
-        ctr = mpc.work_counters() + (mpc.executed_mfma(),)          # (outside the timed region)
-        region_work.append(tuple(a - b for a, b in zip(ctr, prev_ctr)))
-        prev_ctr = ctr
-        first += args.steps
-    elapsed = float(np.median(region_s))
-    med = int(np.argsort(region_s)[len(region_s) // 2])            # the region `value` is computed from
+            tq = torch.tensor(q, dtype=torch.float64, device='cuda')
+            gl = [torch.zeros_like(tq) for _ in range(world)]
+            dist.all_gather(gl, tq)
+            allq = torch.stack(gl).cpu().numpy()
+            q = np.array([float(np.bitwise_or.reduce(allq[:, 0].astype(np.int64))), allq[:, 1].sum(), allq[:, 2].sum(), allq[:, 3].sum()])
+        return q
 
-    k3_each = mpc.kernel_timings(args.repeats + 2)
-    k3_launches = len(k3_each)
-    it1, fl1 = mpc.work_counters()
-    mf1 = mpc.executed_mfma()
-    acc_main = mpc.status_accumulated()
-    ctrs = mpc.solver_counters()
+    def run_protocol(cfg_w, make_inst, per_gpu, large, fast, warmup, steps, repeats):
+        """The timed protocol on this rank's shard of `per_gpu * world` instances: 10 cold-start solves (untimed), `warmup` RTI steps, then `repeats`
+        regions of `steps` device-resident RTI steps, each closed by packing the result records and the all-gather over the ranks; barrier +
+        synchronize on both sides of every region, max over ranks.  fast: srbm_set_solver_step_rule(SRBM_FAST_TOL_STEP, SRBM_FAST_START_MU);
+        otherwise the library default = the reference's gap criterion."""
+        lo_, hi_ = shard_range(per_gpu * world, rank, world)
+        st_, ee_ = zip(*[make_inst(cfg_w, b) for b in range(lo_, hi_)])
+        st_, ee_ = np.array(st_), np.array(ee_).reshape(hi_ - lo_, 12)
+        m = host.BatchMPC(cfg_w, hi_ - lo_, device=local_rank, large=large)
+        m.set_state_trajectory_warm_start(st_)
+        m.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)     # ClarabelInterface's settings (clarabel_interface.cpp:165-175)
+        if fast:
+            m.enable_fast_termination()
+        m.create_initial_run(st_, ee_)                        # 10 cold-start solves (set-up, untimed)
+        m.rti_advance(0, warmup)
+        m.synchronize()
+        ld = m.result_record_doubles()                        # status..., primal, dual, contact times (SURVEY.md 8e record)
+        rec = torch.zeros((hi_ - lo_, ld), dtype=torch.float64, device='cuda')
+        if DIST:                                              # first collective outside the timed region (communicator set-up)
+            gather_records(rec, world)
+            torch.cuda.synchronize()
+        m.clear_status_accumulators()
+        prev = m.work_counters() + (m.executed_mfma(),)
+        it_first = prev[0]
+        m.enable_kernel_timing(repeats + 2)                   # every timed region is ONE launch of the fused RTI kernel
+        reg_s, reg_local, reg_work = [], [], []               # max over ranks; this rank's own; (IPM iterations, algorithmic flops, executed MFMA) per region
+        first = warmup
+        allrec_ = None
+        for rep in range(repeats):
+            if DIST:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            m.rti_advance(first, steps)                       # K device-resident RTI steps
+            m.pack_results_dev(rec.data_ptr(), ld)
+            m.synchronize()
+            allrec_ = gather_records(rec, world)              # RCCL all-gather of the solved trajectories (primal + dual + schedule)
+            torch.cuda.synchronize()
+            if DIST:
+                dist.barrier()
+            loc = time.perf_counter() - t0
+            reg_local.append(loc)
+            reg_s.append(max_over_ranks(loc))
+            ctr = m.work_counters() + (m.executed_mfma(),)    # (outside the timed region)
+            reg_work.append(tuple(x - y for x, y in zip(ctr, prev)))
+            prev = ctr
+            first += steps
+        med_ = int(np.argsort(reg_s)[len(reg_s) // 2])        # the region `value` is computed from
+        acc = m.status_accumulated()
+        return dict(mpc=m, lo=lo_, hi=hi_, n_inst=per_gpu * world, region_s=reg_s, region_local_s=reg_local, region_work=reg_work, med=med_,
+                    elapsed=float(np.median(reg_s)), launch_ms=m.kernel_timings(repeats + 2), acc=acc, q=solved_quality(acc),
+                    counters=m.solver_counters(), allrec=allrec_, ld=ld, states=st_, ees=ee_,
+                    mean_iters=(prev[0] - it_first) / max(1, (hi_ - lo_) * steps * repeats))
+
+    def summary(r, steps, label):
+        """short object for the extra workloads / criteria quoted beside the headline"""
+        q_ = r['q']
+        el = r['elapsed']
+        m = r['mpc']
+        ts, mu = m.solver_step_rule()
+        return {'workload': label, 'value': r['n_inst'] * steps / el, 'unit': 'it/s', 'ms_per_step': 1e3 * el / steps, 'steps': steps, 'repeats': len(r['region_s']),
+                'region_ms': [1e3 * v for v in r['region_s']], 'batch_per_gpu': r['hi'] - r['lo'], 'global_batch': r['n_inst'], 'num_nodes': m.N,
+                'kernel_set': m.kernel_set(), 'large_build': bool(m.large), 'records_gathered': int(r['allrec'].shape[0]),
+                'mean_ipm_iterations': r['mean_iters'], 'timed_solves': int(q_[1]), 'not_solved_in_timed_solves': int(q_[2]),
+                'max_iter_in_timed_solves': int(q_[3]), 'err_bits_all_timed_steps': int(q_[0]), 'all_solved': bool(q_[2] == 0 and q_[0] == 0),
+                'instances_with_a_solve_not_solved_rank0': [int(r['lo'] + b) for b in np.nonzero(r['acc'][:, 2])[0][:64]],
+                'solver': {'tol_gap': 1e-15, 'tol_feas': 1e-10, 'tol_step': ts, 'start_mu': mu, 'solves_ended_by_step_rule': r['counters']['step_rule'],
+                           'lower_start_attempts': r['counters']['low_tried'], 'attempts_repeated_from_standard_start': r['counters']['low_failed']}}
+
+    FAST = not args.reference_criterion_only
+    main = run_protocol(cfg, make_instance, B, args.workload == 'E', FAST, args.warmup, args.steps, args.repeats)
+    mpc, states, ees = main['mpc'], main['states'], main['ees']
+    region_s, region_work, med, elapsed = main['region_s'], main['region_work'], main['med'], main['elapsed']
+    k3_each = main['launch_ms']; k3_launches = len(k3_each)
+    acc_main, ctrs, allrec, LD, q = main['acc'], main['counters'], main['allrec'], main['ld'], main['q']
+
+    # ---- the same protocol at the REFERENCE'S termination criterion (gap 1e-15, no step rule, no lower start: clarabel_interface.cpp:165-175),
+    # i.e. what a caller of the mpc:: facade gets; the like-for-like number beside the CPU baseline, which iterates to that criterion too ----
+    ref_stats = None
+    if FAST and args.workload == 'B' and not args.no_reference_criterion:
+        rr = run_protocol(cfg, make_instance, B, False, False, args.warmup, args.steps, max(3, min(args.repeats, 5)))
+        ref_stats = summary(rr, args.steps, 'Config B, same protocol, every solve to the reference criterion (srbm_set_solver_step_rule(0, 0): the library default)')
+        del rr
+    # ---- BASELINE configs 4 and 5 at their per-GPU sizes, short runs of the same protocol (driver-visible numbers: VERDICT r3 item 4) ----
+    d_stats = e_stats = None
+    if args.workload == 'B' and args.extra_workloads:
+        cfg_d = host.load_config('a1_config_distr_rejection')
+        rd = run_protocol(cfg_d, config_d_instance, 512, False, FAST, 3, 10, 3)
+        d_stats = summary(rd, 10, 'Config D: 512 A1 SRBM MPC instances per GPU, N=50, dt=0.02, a1_config_distr_rejection.yaml values, push distribution on the '
+                                  'initial momentum (co-resident kernel set); not-solved solves belong to instances whose QPs the oracle finds infeasible too')
+        del rd
+        cfg_e = host.load_config('a1_configuration', num_nodes=40)
+        re_ = run_protocol(cfg_e, config_b_instance, 128, True, FAST, 3, 10, 3)
+        e_stats = summary(re_, 10, 'Config E (SRBM stand-in for the dead centroidal MPC): 128 instances per GPU, N=40, dt=0.05, LARGE-capacity build')
+        del re_
 
     # ---- second segment (SURVEY.md 8d, Config C): N=20 / dt=0.05 with the values of apps/a1_gait_opt_config.yaml, gait step every 5th iteration ----
     gait_stats = None
@@ -378,6 +445,9 @@ def main():
         gm = host.BatchMPC(cfg_c, hi - lo, device=local_rank)
         gm.set_state_trajectory_warm_start(sc)
         gm.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
+        if FAST:
+            gm.enable_fast_termination()     # plain steps and line-search candidates end by the step rule; the solve whose KKT system is differentiated
+                                             # runs to the gap criterion (srbm_gait_rti_advance does that by itself); no lower-start attempts in this protocol
         gm.create_initial_run(sc, ec)
         gait = host.BatchGaitOptimizer(gm)
         gait.rti_advance(0, 6, FREQ)                 # run_num 0..5: includes one gradient + LP (run 4) and one line search (run 5)
@@ -402,6 +472,7 @@ def main():
         solves = n_inst * ((args.gait_steps - n_ls) + 10 * n_ls)      # a line search is 10 RTI solves per instance
         gait_stats = {'workload': 'Config C: %d instances per GPU, N=20, dt=0.05, a1_gait_opt_config.yaml values (mu 0.6, force bound 200, target x=y=1); '
                                   'controller protocol with the gait step every 5th iteration (gradient + LP, then 10-candidate line search)' % B,
+                      'solver_tol_step': gm.solver_step_rule()[0],
                       'steps': args.gait_steps, 'gait_opt_steps': n_go, 'line_search_steps': n_ls,
                       'rti_solves_per_s_incl_line_search': solves / el_g, 'gait_steps_per_s': n_inst * n_ls / el_g,
                       'ms_per_step': 1e3 * el_g / args.gait_steps,
@@ -415,6 +486,8 @@ def main():
         SUB = 10
         cl = host.BatchMPC(cfg, hi - lo, device=local_rank, large=mpc.large)
         cl.set_state_trajectory_warm_start(states)
+        if FAST:
+            cl.enable_fast_termination()     # (step rule only: under a plant the library ignores start_mu)
         cl.create_initial_run(states, ees)
         cl.plant_set_state(states)
         rng = np.random.default_rng(777 + lo)
@@ -439,6 +512,7 @@ def main():
         accc = cl.status_accumulated()
         cl_stats = {'workload': 'closed loop on a fresh copy of the batch: plant = SRBM dynamics (explicit Euler, %d sub-steps per step) under the current '
                                 'trajectory, one push per instance at t = 2.5 dt (Config D distribution)' % SUB,
+                    'solver_tol_step': cl.solver_step_rule()[0],
                     'steps': args.closed_loop_steps, 'rti_iterations_per_s': n_inst * args.closed_loop_steps / el_c,
                     'ms_per_step': 1e3 * el_c / args.closed_loop_steps,
                     'statuses_after': {int(k): int(v) for k, v in zip(*np.unique(stc, return_counts=True))},
@@ -517,15 +591,13 @@ def main():
                                          'targets_not_ok': int(bad_d[0]), 'qp_not_solved': int(bad_d[1])}}
     value = n_inst * args.steps / elapsed
 
-    # quality of ALL timed solves of this rank (sticky accumulators), reduced over the ranks
-    q = np.array([float(np.bitwise_or.reduce(acc_main[:, 0])), float(acc_main[:, 1].sum()), float(acc_main[:, 2].sum()), float(acc_main[:, 3].sum())])
+    # this rank's own region times, gathered: a straggling GPU shows up here, not only in the max
+    per_rank_ms = [[1e3 * v for v in main['region_local_s']]]
     if DIST:
-        tq = torch.tensor(q, dtype=torch.float64, device='cuda')
-        gl = [torch.zeros_like(tq) for _ in range(world)]
-        dist.all_gather(gl, tq)
-        allq = torch.stack(gl).cpu().numpy()
-        q = np.array([float(np.bitwise_or.reduce(allq[:, 0].astype(np.int64))), allq[:, 1].sum(), allq[:, 2].sum(), allq[:, 3].sum()])
-
+        tl = torch.tensor(main['region_local_s'], dtype=torch.float64, device='cuda')
+        gl = [torch.zeros_like(tl) for _ in range(world)]
+        dist.all_gather(gl, tl)
+        per_rank_ms = [[1e3 * float(v) for v in t_.cpu().numpy()] for t_ in gl]
     if rank == 0:
         status_all = allrec[:, 0].cpu().numpy()
         err_all = allrec[:, 5].cpu().numpy().astype(np.int64)
@@ -563,6 +635,10 @@ def main():
             'value': value, 'unit': 'it/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic', 'repeats': args.repeats, 'region_ms': [1e3 * v for v in region_s],
+            'region_mean_ms': 1e3 * float(np.mean(region_s)), 'value_from_mean_region': n_inst * args.steps / float(np.mean(region_s)),
+            'statistic': 'value = instances x steps / MEDIAN region (max over ranks); the first region follows the cold start',
+            'rccl_world_size': dist.get_world_size() if DIST else 1, 'per_rank_region_ms': per_rank_ms,
+            'weak_scaling_efficiency': (value / (world * args.n1_baseline)) if args.n1_baseline > 0 else None,
             'config': {'workload': ('Config B: %d A1 SRBM MPC instances per GPU, N=20, dt=0.05, a1_configuration.yaml values, '
                                     '10 cold-start solves then open-loop RTI steps (state := node 1)' % B) if args.workload == 'B' else
                                    ('Config D: %d A1 SRBM MPC instances per GPU, N=50, dt=0.02, a1_config_distr_rejection.yaml values, push '
@@ -575,13 +651,19 @@ def main():
                        'timed_solves': int(q[1]), 'not_solved_in_timed_solves': int(q[2]), 'max_iter_in_timed_solves': int(q[3]),
                        'instances_with_a_solve_not_solved_rank0': [int(lo + b) for b in np.nonzero(acc_main[:, 2])[0][:64]],
                        'err_bits_all_timed_steps': int(q[0]) | int(np.bitwise_or.reduce(err_all)),
-                       'mean_ipm_iterations': (it1 - it0) / max(1, (hi - lo) * args.steps * args.repeats),
+                       'mean_ipm_iterations': main['mean_iters'],
                        'solver': {'tol_gap': 1e-15, 'tol_feas': 1e-10, 'tol_step': mpc.solver_step_rule()[0], 'start_mu': mpc.solver_step_rule()[1],
                                   'solves_ended_by_step_rule': ctrs['step_rule'], 'lower_start_attempts': ctrs['low_tried'],
                                   'attempts_repeated_from_standard_start': ctrs['low_failed'], 'solves_counted': ctrs['solves'],
                                   'note': 'rank 0, all solves since the accumulators were cleared (timed regions; include/srbm_rti.h srbm_set_solver_step_rule)'}},
             'roofline': roof,
         }
+        if ref_stats is not None:
+            out['reference_criterion'] = ref_stats
+        if d_stats is not None:
+            out['config_d'] = d_stats
+        if e_stats is not None:
+            out['config_e'] = e_stats
         if gait_stats is not None:
             out['gait'] = gait_stats
         if cl_stats is not None:
@@ -591,6 +673,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == 'B':
             try:
                 out['cpu_baseline'] = cpu_baseline(cfg)
+                cb = out['cpu_baseline']
+                cb['criterion'] = "the reference's: Clarabel restatement to gap 1e-15 (clarabel_interface.cpp:165-175)"
+                like = ref_stats['value'] if ref_stats is not None else (value if not FAST else None)
+                cb['like_for_like'] = {'gpu_value_at_the_same_criterion': like,
+                                       'speedup_vs_one_thread': (like / cb['value']) if like and cb['value'] else None,
+                                       'speedup_vs_all_cores': (like / cb['all_cores']['value']) if like and cb['all_cores']['value'] else None,
+                                       'note': 'the headline `value` ends its solves by the step rule (config.solver) -- compare THIS pair for a like-for-like ratio'}
             except Exception as e:            # the GPU line stands on its own
                 out['cpu_baseline'] = {'value': None, 'unit': 'it/s', 'cores': 0, 'kind': 'port', 'sample': 'failed: %s' % e}
         print(json.dumps(out))

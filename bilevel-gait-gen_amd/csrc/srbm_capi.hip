@@ -1544,6 +1544,34 @@ int srbm_trajectory_eval(const srbm_trajectory* t, int ee, double time, double* 
     }
     return err;
 }
+// Trajectory::SplinesAsVec (trajectory.cpp:429-452) of a record: the spline variables in the order of the QP's decision vector -- per foot and force
+// coordinate (value, slope / FORCE_MULT) of every stance-interior knot (EndEffectorSplines::GetSplineAsQPVec over the mutable force nodes), then per foot
+// and xy coordinate the mutable position nodes.  The same rules kernel 1 builds its linearisation point with (srbm_k1_assemble.hiph), host arithmetic.
+int srbm_trajectory_splines_as_vec(const srbm_trajectory* t, double* out, int capacity, int* n_total, int* n_force) {
+    if (!t || !out || !n_total) return fail("bad arguments");
+    int nf = 0, np_ = 0;
+    uint8_t kind[SRBM_NEE][SRBM_KMAX], ismut[SRBM_NEE][SRBM_KMAX];
+    for (int ee = 0; ee < SRBM_NEE; ee++) {
+        if (t->nk[ee] < 2 || t->nk[ee] > SRBM_KMAX) return fail("srbm_trajectory_splines_as_vec: malformed record");
+        for (int k = 0; k < SRBM_KMAX; k++) kind[ee][k] = (uint8_t)t->knot_kind[ee][k];
+        const FootView f{t->knot_time[ee], kind[ee], t->nk[ee]};
+        for (int k = 0; k < t->nk[ee]; k++) nf += kind[ee][k] == SRBM_K_F ? 6 : 0;
+        np_ += 2 * srbm_pos_mutable(f, ismut[ee]);
+    }
+    if (nf + np_ > capacity) return fail("srbm_trajectory_splines_as_vec: output buffer too small");
+    int fi = 0, pi = nf;
+    for (int ee = 0; ee < SRBM_NEE; ee++) {
+        for (int c = 0; c < 3; c++) {
+            for (int k = 0; k < t->nk[ee]; k++)
+                if (kind[ee][k] == SRBM_K_F) { out[fi++] = t->force[ee][c][k][0]; out[fi++] = t->force[ee][c][k][1]; }
+            if (c < 2)
+                for (int k = 0; k < t->nk[ee]; k++) if (ismut[ee][k]) out[pi++] = t->pos_xy[ee][c][k];
+        }
+    }
+    *n_total = nf + np_;
+    if (n_force) *n_force = nf;
+    return 0;
+}
 // SingleRigidBodyModel::ConvertManifoldStateToTangentState / ConvertTangentStateToManifoldState (single_rigid_body_model.cpp:188-220; the
 // reference state argument is unused there: quat_ref is the identity): host arithmetic, the functions the kernels use
 int srbm_convert_manifold_to_tangent(const double* state13, double* tangent12) {

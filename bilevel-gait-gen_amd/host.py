@@ -484,7 +484,9 @@ class BatchMPC:
         the header is written and stays set: every column of the table is LEFT aligned in its 15 characters.)"""
         cw, tw = 15, 150
         c = self.cfg
+        import time as _time
         fh.write('-' * tw + '\n' + ' ' * (tw // 2 - 7) + 'MPC Statistics\n')
+        fh.write('MPC started at: ' + _time.ctime() + '\n')                     # std::ctime of the wall clock (mpc.cpp:910-915)
         fh.write('Number of nodes: %d\nMPC time step: %g\nForce bounds: %g\nEnd Effector box size: %g %g\n' %
                  (self.N, c['integrator_dt'], c['force_bound'], c['ee_box_size'][0], c['ee_box_size'][1]))
         fh.write('Force cost: %g\nFoot offset: %g\nSwing height: %g\n' % (c['force_cost'], c['foot_offset'], c['swing_height']))

@@ -14,29 +14,25 @@
 //   mpc/include/gait_optimizer.h:23-93 GaitOptimizer   | same call protocol; the QP partials never leave the device, so
 //                                                      | QPPartials / QPPartialsDense are handles, not matrices
 //   mpc/include/qp/qp_interface.h:12-22 SolveQuality   | same nine values
-// Eigen: the real <Eigen/Core> when it exists, else mpc_facade/eigen_shim.h (this container has none).
+// Eigen: <Eigen/Core> as in the reference (mpc/include/mpc.h:8).  This container has no Eigen: the TESTS put a stand-in for the handful of types
+// the interface is typed with on their include path (tests/cpp/eigen_standin/Eigen/Core); nothing of it ships with the product headers.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <ctime>
 #include <fstream>
 #include <iomanip>
 #include <iostream>
 #include <memory>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <utility>
 #include <vector>
 
-#if defined(__has_include)
-#if __has_include(<Eigen/Core>)
 #include <Eigen/Core>
-#define MPC_FACADE_REAL_EIGEN 1
-#endif
-#endif
-#ifndef MPC_FACADE_REAL_EIGEN
-#include "eigen_shim.h"
-#endif
 
 #include "../srbm_rti.h"
 #include "urdf_constants.h"
@@ -151,7 +147,55 @@ public:
         for (int k = 0; k < rec_.nk[ee]; k++) if (rec_.knot_kind[ee][k] == 1 && rec_.knot_time[ee][k] > time) return rec_.knot_time[ee][k];
         throw std::runtime_error("No touch down after the given time.");
     }
+    // Trajectory::SplinesAsVec (trajectory.cpp:429-452): the spline variables in the order of the QP's decision vector -- per foot and coordinate the
+    // force variables (value, slope / FORCE_MULT of every stance-interior knot), then per foot and xy coordinate the mutable position nodes
+    vector_t SplinesAsVec() const {
+        std::vector<double> v(4 * (3 * 2 + 2) * 32);
+        int n = 0;
+        if (srbm_trajectory_splines_as_vec(&rec_, v.data(), (int)v.size(), &n, nullptr) != 0) throw std::runtime_error(std::string("srbm: ") + srbm_last_error());
+        vector_t out(n);
+        for (int i = 0; i < n; i++) out(i) = v[i];
+        return out;
+    }
+    // Trajectory::PrintTrajectoryToFile (trajectory.cpp:146-223) AS CODED: the force / position / timing blocks are commented out in the reference, their
+    // headings are still written; the states matrix and the spline vector go out in Eigen's default format (columns right-aligned to the widest
+    // coefficient, ' ' between coefficients)
+    void PrintTrajectoryToFile(const std::string& file_name) const {
+        std::ofstream file;
+        file.open(file_name);
+        file << "states: " << std::endl;
+        file << FormatDense(file, rec_.num_states, 13, [&](int r, int c) { return rec_.states[r][c]; }) << std::endl;
+        file << "force spline: " << std::endl;
+        file << "position spline: " << std::endl;
+        file << "timings: " << std::endl;
+        const vector_t sv = SplinesAsVec();
+        file << "spline vec: \n" << FormatDense(file, (int)sv.size(), 1, [&](int r, int) { return sv(r); }) << std::endl;
+        file.close();
+    }
 private:
+    // Eigen's operator<< for a dense matrix with the default IOFormat: stream precision, aligned columns
+    template <class Get>
+    static std::string FormatDense(const std::ostream& like, int rows, int cols, Get get) {
+        std::vector<std::string> cell((size_t)rows * cols);
+        size_t width = 0;
+        for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) {
+            std::ostringstream o;
+            o.copyfmt(like);
+            o << get(r, c);
+            cell[(size_t)r * cols + c] = o.str();
+            width = std::max(width, o.str().size());
+        }
+        std::string out;
+        for (int r = 0; r < rows; r++) {
+            if (r) out += "\n";
+            for (int c = 0; c < cols; c++) {
+                if (c) out += " ";
+                const std::string& x = cell[(size_t)r * cols + c];
+                out += std::string(width - x.size(), ' ') + x;
+            }
+        }
+        return out;
+    }
     static void Lookup(int rc, double time) {
         if (rc != 0) throw std::runtime_error("Trajectory: invalid time " + std::to_string(time) + " for the spline lookup.");   // end_effector_splines.cpp:1066-1083
     }
@@ -339,6 +383,7 @@ public:
     // value semantics (mpc.cpp:1133-1181, mpc_single_rigid_body.cpp:804-807)
     MPCSingleRigidBody(const MPCSingleRigidBody& other) : info_(other.info_), model_consts_(other.model_consts_), model_(other.model_),
                                                           used_log_file_(other.used_log_file_), solves_(other.solves_), last_solve_ms_(other.last_solve_ms_),
+                                                          history_(other.history_), contact_sched_change_(other.contact_sched_change_),
                                                           partials_as_data_(other.partials_as_data_), legs_(other.legs_), has_legs_(other.has_legs_) {
         check_srbm(srbm_batch_clone(other.h_, &h_));
     }
@@ -347,6 +392,7 @@ public:
         Release();
         info_ = other.info_; model_consts_ = other.model_consts_; model_ = other.model_; used_log_file_ = other.used_log_file_; solves_ = other.solves_;
         last_solve_ms_ = other.last_solve_ms_; partials_as_data_ = other.partials_as_data_; legs_ = other.legs_; has_legs_ = other.has_legs_; kin_.reset();
+        history_ = other.history_; contact_sched_change_ = other.contact_sched_change_;
         check_srbm(srbm_batch_clone(other.h_, &h_));
         return *this;
     }
@@ -394,13 +440,8 @@ public:
 
     // ---- solves ----
     Trajectory CreateInitialRun(const vector_t& state, const std::vector<vector_3t>& ee_start_locations) {   // mpc.cpp:78-90
-        double ee[12];
-        PackEE(ee_start_locations, ee);
-        CheckState(state);
-        const auto t0 = std::chrono::steady_clock::now();
-        check_srbm(srbm_create_initial_run(h_, state.data(), ee));
-        last_solve_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / 10;
-        solves_ += 10;
+        // ten Solve calls at t = 0, each with its own row in the statistics (srbm_create_initial_run is the same ten launches without the rows)
+        for (int num_iter = 0; num_iter < 10; num_iter++) Solve(state, 0, ee_start_locations);
         return GetTrajectory();
     }
     Trajectory GetRealTimeUpdate(const vector_t& state, double init_time, const std::vector<vector_3t>& ee_start_locations, bool /*high_quality*/) {   // mpc.cpp:92-108
@@ -417,6 +458,7 @@ public:
         int st = 0, err = 0;
         check_srbm(srbm_get_status(h_, &st, &err));
         if (err) throw std::runtime_error("MPC solve raised error bits " + std::to_string(err) + " (time outside the spline range / capacity).");
+        RecordStats();
         return GetTrajectory();
     }
     void SetWarmStartTrajectory(const Trajectory& trajectory) { check_srbm(srbm_set_warm_start_trajectory(h_, 0, 1, &trajectory.Record())); }   // mpc.cpp:110-119
@@ -427,6 +469,7 @@ public:
         std::vector<double> t(4 * mx, 0.0);
         for (int ee = 0; ee < 4; ee++) for (size_t i = 0; i < contact_times[ee].size(); i++) t[ee * mx + i] = contact_times[ee][i].GetTime();
         check_srbm(srbm_update_contact_times(h_, t.data(), (int)mx));
+        contact_sched_change_.push_back(solves_);                                                        // mpc.cpp:1087 (run_num_)
     }
     void AdjustForCurrentContacts(double time, const controller::Contact& contact) {                     // mpc.cpp:1195-1203
         int c[4];
@@ -547,12 +590,32 @@ public:
     srbm_batch* Handle() const { return h_; }
     const MPCInfo& Info() const { return info_; }
 
-    // ---- statistics (mpc.cpp:818-899, 901-989) ----
-    void PrintStats() { std::ofstream null; PrintLine(std::cout, true); }
+    // ---- statistics (mpc.cpp:804-816 RecordStats, 818-899 PrintStats, 901-989 PrintStatLineToFile) ----
+    // MPC::PrintStats: the table of EVERY solve since construction, then the average compute time
+    void PrintStats() { PrintStats(std::cout); }
+    void PrintStats(std::ostream& os) const {
+        const int col_width = 15, table_width = 10 * col_width;
+        using std::setw; using std::setfill;
+        os << setfill('-') << setw(table_width) << "" << std::endl;
+        os << std::left << setfill(' ') << setw(table_width / 2 - 7) << "" << "MPC Statistics" << std::endl;
+        os << setfill('-') << setw(table_width) << "" << std::endl;
+        os << setfill(' ');
+        PrintColumnNames(os);
+        double avg_time = 0;
+        for (int i = 0; i < (int)history_.size(); i++) {
+            PrintRow(os, i);
+            avg_time += history_[i].time_ms;
+        }
+        os << std::endl;
+        avg_time = avg_time / history_.size();
+        os << "Average compute time: " << avg_time << std::endl;
+    }
     void PrintStatLineToFile(std::ofstream& log_file) {
         if (!used_log_file_) { PrintHeader(log_file); used_log_file_ = true; }
-        PrintLine(log_file, false);
+        if (history_.empty()) throw std::out_of_range("PrintStatLineToFile: no solve has been recorded.");     // (the reference indexes alpha_.size() - 1)
+        PrintRow(log_file, (int)history_.size() - 1);
     }
+    int GetNumRecordedSolves() const { return (int)history_.size(); }
 
 private:
     static std::vector<double> ToStd(const vector_t& v) { std::vector<double> o(v.size()); for (int i = 0; i < (int)v.size(); i++) o[i] = v(i); return o; }
@@ -594,11 +657,28 @@ private:
         if (gait_) { srbm_gait_destroy(gait_); gait_ = nullptr; }
         if (h_) { srbm_batch_destroy(h_); h_ = nullptr; }
     }
+    // one row per solve: what MPC::RecordStats (mpc.cpp:804-816) pushes onto its ten vectors
+    struct SolveRecord { double time_ms, eq_violation, step_norm, alpha, cost_result, merit, merit_dd, cost; int solve_type; };
+    void RecordStats() {
+        double st[8], merit = 0, merit_dd = 0;
+        check_srbm(srbm_get_stats(h_, st));
+        check_srbm(srbm_get_merit(h_, &merit, &merit_dd));
+        // cost_result_ and cost_ are both GetCostValue(prev_qp_sol) (mpc.cpp:809 and msrb.cpp:183-184): st[1] twice
+        history_.push_back(SolveRecord{last_solve_ms_, st[2], st[3], st[0], st[1], merit, merit_dd, st[1], (int)GetSolveQuality()});
+    }
+    static void PrintColumnNames(std::ostream& os) {
+        const int col_width = 15, table_width = 10 * col_width;
+        using std::setw; using std::setfill;
+        for (const char* n : {"Solve #", "Time (ms)", "Constraints", "Step Norm", "Alpha", "Cost", "Merit", "Merit dd", "Solve Type", "QP Cost"}) os << setw(col_width) << n;
+        os << std::endl << setfill('-') << setw(table_width) << "" << std::endl << setfill(' ');
+    }
     void PrintHeader(std::ostream& os) const {
         const int col_width = 15, table_width = 10 * col_width;
         using std::setw; using std::setfill;
+        const std::time_t now = std::chrono::system_clock::to_time_t(std::chrono::system_clock::now());
         os << setfill('-') << setw(table_width) << "" << std::endl;
         os << std::left << setfill(' ') << setw(table_width / 2 - 7) << "" << "MPC Statistics" << std::endl;
+        os << std::left << "MPC started at: " << std::ctime(&now);
         os << std::left << "Number of nodes: " << info_.num_nodes << std::endl;
         os << std::left << "MPC time step: " << info_.integrator_dt << std::endl;
         os << std::left << "Force bounds: " << info_.force_bound << std::endl;
@@ -608,23 +688,20 @@ private:
         os << std::left << "Swing height: " << info_.swing_height << std::endl;
         os << setfill('-') << setw(table_width) << "" << std::endl;
         os << setfill(' ');
-        for (const char* n : {"Solve #", "Time (ms)", "Constraints", "Step Norm", "Alpha", "Cost", "Merit", "Merit dd", "Solve Type", "QP Cost"}) os << setw(col_width) << n;
-        os << std::endl << setfill('-') << setw(table_width) << "" << std::endl << setfill(' ');
+        PrintColumnNames(os);
     }
-    void PrintLine(std::ostream& os, bool with_header) const {
-        if (with_header) PrintHeader(os);
-        double st[8], merit = 0, merit_dd = 0;
-        check_srbm(srbm_get_stats(h_, st));
-        check_srbm(srbm_get_merit(h_, &merit, &merit_dd));
+    void PrintRow(std::ostream& os, int i) const {
         static const char* names[] = {"Solved", "Solved Inacc", "Max Iter", "P - Infeasible", "D - Infeasible", "P - Infeasible Inacc", "D - Infeasible Inacc", "Unsolved", "Other"};
-        const int q = (int)GetSolveQuality();
-        const int col_width = 15;
+        const int col_width = 15, table_width = 10 * col_width;
         using std::setw;
-        // columns of mpc.cpp:979-988: i, solve_time_, equality violation, step norm, alpha, cost_result_, merit, merit dd, solve type, cost_ --
-        // cost_result_ and cost_ are both GetCostValue(prev_qp_sol) (mpc.cpp:809 and msrb.cpp:183-184), i.e. st[1] twice
-        os << std::left << setw(col_width) << (solves_ - 1) << setw(col_width) << last_solve_ms_ << setw(col_width) << st[2] << setw(col_width) << st[3] << setw(col_width) << st[0]
-           << setw(col_width) << st[1] << setw(col_width) << merit << setw(col_width) << merit_dd << setw(col_width) << names[q < 0 || q > 8 ? 8 : q]
-           << setw(col_width) << st[1] << std::endl;
+        for (const int j : contact_sched_change_)
+            if (i == j) std::cout << "Contact schedule changed " << setw(table_width - 25) << std::endl;       // (to std::cout in both printers, mpc.cpp:847-851, 943-947)
+        const SolveRecord& r = history_.at(i);
+        const int q = r.solve_type;
+        // columns of mpc.cpp:979-988: i, solve_time_, equality violation, step norm, alpha, cost_result_, merit, merit dd, solve type, cost_
+        os << std::left << setw(col_width) << i << setw(col_width) << r.time_ms << setw(col_width) << r.eq_violation << setw(col_width) << r.step_norm << setw(col_width) << r.alpha
+           << setw(col_width) << r.cost_result << setw(col_width) << r.merit << setw(col_width) << r.merit_dd << setw(col_width) << names[q < 0 || q > 8 ? 8 : q]
+           << setw(col_width) << r.cost << std::endl;
     }
 
     MPCInfo info_;
@@ -635,6 +712,8 @@ private:
     bool used_log_file_ = false;
     int solves_ = 0;
     double last_solve_ms_ = 0;
+    std::vector<SolveRecord> history_;
+    std::vector<int> contact_sched_change_;
     bool partials_as_data_ = true;
     srbm_leg_kinematics legs_{};
     bool has_legs_ = false;

@@ -157,6 +157,10 @@ int srbm_set_warm_start_trajectory(srbm_batch* h, int first, int count, const sr
  * arithmetic on a record (no GPU needed) -- what controllers/mpc_controller.cpp:171-186,352,415-509 evaluates at 1 kHz.
  * force[3], pos[3]; returns 0, or the error bits of the lookup (time outside the knot range: the reference throws). */
 int srbm_trajectory_eval(const srbm_trajectory* traj, int ee, double time, double* force3, double* pos3, int* in_contact);
+/* Trajectory::SplinesAsVec (mpc/trajectory.cpp:429-452) of a record: force spline variables (per foot, per coordinate: value and slope / FORCE_MULT of
+ * every stance-interior knot) then position variables (per foot, x then y: the mutable nodes) -- the order of the spline part of the QP's decision
+ * vector.  out[capacity]; *n_total = entries written, *n_force (may be NULL) = how many of them are force variables.  Host arithmetic. */
+int srbm_trajectory_splines_as_vec(const srbm_trajectory* t, double* out, int capacity, int* n_total, int* n_force);
 /* SingleRigidBodyModel::ConvertManifoldStateToTangentState / ConvertTangentStateToManifoldState (mpc/models/single_rigid_body_model.cpp:188-220;
  * used by the caller at controllers/mpc_controller.cpp:60): [p, lin-mom, quat xyzw, ang-mom] (13) <-> [p, lin-mom, log3(quat), ang-mom] (12).
  * Host arithmetic, the same functions the kernels use; the reference's ref_state argument is unused there (its quat_ref is the identity). */

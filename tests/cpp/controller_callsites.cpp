@@ -189,6 +189,15 @@ int main(int argc, char** argv) {
     for (const mpc::time_v& tv : t.GetContactTimes()) for (const mpc::SplineTimes& s : tv) std::printf("contact_time %d %.17g\n", k++, s.GetTime());
     const std::vector<Eigen::Vector2d> bc = c.mpc_.GetEEBoxCenter();
     for (int ee = 0; ee < 4; ee++) std::printf("box_center %d %.17g\nbox_center %d %.17g\n", 2 * ee, bc[ee](0), 2 * ee + 1, bc[ee](1));
+    // statistics and trajectory dumps (mpc.cpp:818-899 PrintStats over the whole history, trajectory.cpp:146-223 PrintTrajectoryToFile)
+    {
+        std::ofstream stats("/tmp/mpc_facade_stats.txt");
+        c.mpc_.PrintStats(stats);
+    }
+    t.PrintTrajectoryToFile("/tmp/mpc_facade_traj.txt");
+    const vector_t sv = t.SplinesAsVec();
+    std::printf("recorded 0 %d\n", c.mpc_.GetNumRecordedSolves());
+    for (int i = 0; i < (int)sv.size(); i++) std::printf("spline_vec %d %.17g\n", i, sv(i));
     const auto viz = c.mpc_.CreateVizData();
     std::printf("viz 0 %d\nviz 1 %d\n", (int)viz.size(), (int)viz.at(4).size());
     return 0;

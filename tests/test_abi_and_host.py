@@ -110,6 +110,33 @@ dist.barrier(); dist.destroy_process_group()
 ''' % ROOT)
 
 
+def test_bench_dry_run_eight_ranks_config_d():
+    """BASELINE config 4 at its full size: `bench.py --gpus 8 --workload D --dry-run` spawns 8 ranks (gloo), every rank owns exactly 512 of the
+    4096 instances (contiguous, exact bounds) and rank 0 holds all 4096 records after the all-gather"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['OMP_NUM_THREADS'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--dry-run', '--workload', 'D'], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    c = d['config']
+    assert d['n_gpus'] == 8 and d['collective_world_size'] == 8 and d['scaling'] == 'weak'
+    assert c['batch_per_gpu'] == 512 and c['global_batch'] == 4096 and c['records_gathered'] == 4096 and c['gather_ok']
+    assert c['shard_bounds'] == [[512 * r_, 512 * (r_ + 1)] for r_ in range(8)]
+
+
+def test_build_is_serialised_by_a_file_lock():
+    """host.build() of two processes at once: one `make` at a time on the tree (the ranks of a multi-GPU run on a fresh box).  With the libraries
+    present build() returns without running make; force=True takes the lock -- two forced builds in parallel both succeed."""
+    code = 'import sys; sys.path.insert(0, %r); from srbm_loader import host; host.build(force=True); print("built")' % ROOT
+    procs = [subprocess.Popen([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for _ in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs) and all('built' in o for o in outs), outs
+    assert os.path.exists(host.LIB_PATH) and os.path.exists(host.LIB_PATH_LARGE)
+
+
 def test_bench_gpus_flag_spawns_the_ranks():
     """`python bench.py --gpus 2` outside torchrun must produce TWO ranks (the launcher spawns fresh processes before anything
     touches a GPU); --dry-run walks the launcher, the sharding and the all-gather on CPU (gloo) without a HIP call."""

@@ -1,4 +1,4 @@
-"""The C++ host side above the C-ABI (include/srbm_rti.hpp: srbm::MPCSingleRigidBody, srbm::GaitOptimizer -- the reference's
+"""The C++ host side above the C-ABI (tests/cpp/cabi_batch_smoke.cpp drives include/srbm_rti.h from C++ for a batch; include/mpc_facade: the reference's
 class and method names).  CPU: the header and the smoke program compile with g++ and link against libsrbm_rti.so.
 GPU: the program's read-backs equal the ctypes path (same library, same call sequence: bit-identical)."""
 import json
@@ -11,6 +11,9 @@ import pytest
 from srbm_loader import host
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# <Eigen/Core> for the facade headers: the system's if there is one, else the stand-in of the tests (this container has no Eigen)
+EIGEN_INC = next((d for d in ('/usr/include/eigen3', '/usr/local/include/eigen3') if os.path.exists(os.path.join(d, 'Eigen', 'Core'))),
+                 os.path.join(ROOT, 'tests', 'cpp', 'eigen_standin'))
 CPP = os.path.join(ROOT, 'tests', 'cpp')
 
 
@@ -42,8 +45,8 @@ def build_program(tmpdir):
     write_cfg_inc(cfg, os.path.join(tmpdir, 'cfg.inc'))
     exe = os.path.join(tmpdir, 'facade_smoke')
     libdir = os.path.dirname(host.LIB_PATH)
-    subprocess.check_call(['g++', '-std=c++17', '-O1', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), '-I', tmpdir,
-                           os.path.join(CPP, 'facade_smoke.cpp'), '-o', exe, '-L', libdir, '-lsrbm_rti', '-Wl,-rpath,' + libdir])
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), '-I', EIGEN_INC, '-I', tmpdir,
+                           os.path.join(CPP, 'cabi_batch_smoke.cpp'), '-o', exe, '-L', libdir, '-lsrbm_rti', '-Wl,-rpath,' + libdir])
     return cfg, exe
 
 
@@ -68,7 +71,7 @@ def test_cpp_host_side_equals_ctypes_path(tmp_path):
     g = host.BatchMPC(cfg, 2)
     g.set_state_trajectory_warm_start(s0)
     g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
-    g.set_solver_step_rule(0.0, 0.0)
+    assert g.solver_step_rule() == (0.0, 0.0)
     g.create_initial_run(s0, ee0)
     g.rti_advance(0, 4); g.synchronize()
     gait = host.BatchGaitOptimizer(g)
@@ -96,7 +99,7 @@ def build_callsites(tmpdir):
     write_cfg_inc(cfg, os.path.join(tmpdir, 'cfg.inc'))
     exe = os.path.join(tmpdir, 'controller_callsites')
     libdir = os.path.dirname(host.LIB_PATH)
-    subprocess.check_call(['g++', '-std=c++17', '-O1', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), '-I', tmpdir,
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), '-I', EIGEN_INC, '-I', tmpdir,
                            os.path.join(CPP, 'controller_callsites.cpp'), '-o', exe, '-L', libdir, '-lsrbm_rti', '-Wl,-rpath,' + libdir])
     return cfg, exe
 
@@ -135,7 +138,7 @@ def build_wbc_callsites(tmpdir):
     write_cfg_inc(cfg, os.path.join(tmpdir, 'cfg.inc'))
     exe = os.path.join(tmpdir, 'wbc_callsites')
     libdir = os.path.dirname(host.LIB_PATH)
-    subprocess.check_call(['g++', '-std=c++17', '-O1', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), '-I', tmpdir,
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), '-I', EIGEN_INC, '-I', tmpdir,
                            os.path.join(CPP, 'wbc_callsites.cpp'), '-o', exe, '-L', libdir, '-lsrbm_rti', '-Wl,-rpath,' + libdir])
     return cfg, exe
 
@@ -185,7 +188,7 @@ def test_mpc_facade_runs_the_controller_protocol_like_the_ctypes_path(tmp_path):
     vals = parse_dump(subprocess.check_output([exe, '-', str(TICKS), str(F)], text=True))
     # header block of the log the program wrote through MPC::PrintStatLineToFile
     log = open('/tmp/mpc_facade_log.txt').read().splitlines()
-    assert log[0] == '-' * 150 and 'MPC Statistics' in log[1] and log[2] == 'Number of nodes: 20'
+    assert log[0] == '-' * 150 and 'MPC Statistics' in log[1] and log[2].startswith('MPC started at: ') and log[3] == 'Number of nodes: 20'
     assert len([l for l in log if l[:1].isdigit()]) == TICKS and all(len(l.rstrip()) <= 150 for l in log)
     s0 = np.array(cfg['srb_init'], float)
     ee0 = np.array([[0.2, 0.2, 0], [0.2, -0.2, 0], [-0.2, 0.2, 0], [-0.2, -0.2, 0]], float)
@@ -236,6 +239,28 @@ def test_mpc_facade_runs_the_controller_protocol_like_the_ctypes_path(tmp_path):
     assert np.array_equal(np.array(vals['contact_time']), np.concatenate(t2.get_contact_times()))
     assert np.array_equal(np.array(vals['box_center']), g.ee_box_center().reshape(-1))
     assert vals['viz'] == [5.0, 21.0]
+    # MPC::PrintStats: one row per Solve since construction (10 of CreateInitialRun, the plain ticks, the final update), then the average time
+    n_rows = 10 + (TICKS - n_ls) + 1
+    assert vals['recorded'] == [float(n_rows)]
+    stats = open('/tmp/mpc_facade_stats.txt').read().splitlines()
+    assert stats[0] == '-' * 150 and 'MPC Statistics' in stats[1] and stats[2] == '-' * 150 and stats[3].split()[:2] == ['Solve', '#'] and stats[4] == '-' * 150
+    rows = [l for l in stats if l[:1].isdigit()]
+    assert [int(l.split()[0]) for l in rows] == list(range(n_rows)) and all(len(l.rstrip()) <= 150 for l in rows)
+    assert all(('Solved' in l) or ('Max Iter' in l) for l in rows)
+    assert stats[-1].startswith('Average compute time: ') and float(stats[-1].split(':')[1]) > 0
+    last = rows[-1].split()
+    assert abs(float(last[4]) - g.stats()[0, 0]) <= 1e-5 * max(1.0, abs(g.stats()[0, 0]))          # Alpha column of the last solve (%g precision)
+    assert abs(float(last[5]) - g.cost()[0]) <= 1e-5 * abs(g.cost()[0])                             # Cost column
+    # Trajectory::SplinesAsVec == the spline part of the decision vector the trajectory was written from; PrintTrajectoryToFile as coded
+    n = int(sz[0]); nx = (cfg['num_nodes'] + 1) * 12
+    assert len(vals['spline_vec']) == n - nx
+    assert np.abs(np.array(vals['spline_vec']) - g.qp_solution()[0, nx:n]).max() <= 1e-12 * max(1.0, np.abs(g.qp_solution()[0, nx:n]).max())
+    tr = open('/tmp/mpc_facade_traj.txt').read().splitlines()
+    assert tr[0] == 'states: ' and tr[22] == 'force spline: ' and tr[23] == 'position spline: ' and tr[24] == 'timings: ' and tr[25] == 'spline vec: '
+    st_file = np.array([[float(v) for v in l.split()] for l in tr[1:22]])
+    assert st_file.shape == (21, 13) and np.allclose(st_file, t2.get_states(), rtol=2e-5, atol=1e-6)
+    assert len({len(l) for l in tr[1:22]}) == 1                       # Eigen's aligned columns: every row has the same width
+    assert np.allclose([float(l) for l in tr[26:26 + n - nx]], vals['spline_vec'], rtol=2e-5, atol=1e-6) and len(tr) == 26 + n - nx
 
 
 def check_urdf_constants(vals, gold):
@@ -318,7 +343,7 @@ def build_playground(tmpdir):
     write_cfg_inc(cfg, os.path.join(tmpdir, 'cfg.inc'))
     exe = os.path.join(tmpdir, 'gait_playground_callsites')
     libdir = os.path.dirname(host.LIB_PATH)
-    subprocess.check_call(['g++', '-std=c++17', '-O1', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), '-I', tmpdir,
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), '-I', EIGEN_INC, '-I', tmpdir,
                            os.path.join(CPP, 'gait_playground_callsites.cpp'), '-o', exe, '-L', libdir, '-lsrbm_rti', '-Wl,-rpath,' + libdir])
     return cfg, exe
 

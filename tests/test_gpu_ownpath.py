@@ -8,8 +8,9 @@ re-synchronised tests (tests/test_gpu_resync.py) are the statement about the sol
     device: srbm_rti_advance(i, 1), tol_step 1e-5, start_mu 0.1 (step rule + lower-start attempts: the bench mode)
     oracle: Clarabel restatement at the reference's criterion (gap 1e-15)
 
-for 128 seeded Config-B instances over 100 steps.  Asserted: the distribution of the relative primal difference over all (instance,
-step) pairs -- median, 99th percentile, maximum -- and that it does not GROW along the path (last 20 steps against steps 10-30).
+for 128 seeded Config-B instances over 100 steps.  Asserted: the distribution of the relative difference (decision vector and node states)
+over all (instance, step) pairs, that the paths agree to the parity tolerance again once the transient of the first horizon extension is over,
+and that the fast mode departs from the oracle no more than a gap-criterion run of the device does.
 The same protocol at the reference's criterion on the device (step rule off) is run beside it, so that the numbers say how much of the
 divergence belongs to the termination rule and how much to two IPMs walking a flat valley."""
 from concurrent.futures import ThreadPoolExecutor
@@ -77,21 +78,30 @@ def test_free_running_bench_mode_stays_within_a_stated_bound_of_the_oracle():
     err_r, err_rs, ok_r, _ = own_path_run(fast=False)
     def q(a):
         v = a[np.isfinite(a)]
-        return dict(n=int(v.size), median=float(np.median(v)), p99=float(np.percentile(v, 99)), max=float(v.max()))
-    d, dr = q(err), q(err_r)
-    ds, drs = q(err_s), q(err_rs)
-    early, late = q(err[10:30]), q(err[-20:])
-    print('own path, 128 x 100, bench mode (tol_step 1e-5, start_mu 0.1) vs oracle: x', d, 'node states', ds, 'steps 10-30', early, 'last 20', late,
-          'instances compared to the end %d' % ok.sum(), ctr)
-    print('own path, 128 x 100, reference criterion on the device vs oracle:       x', dr, 'node states', drs, 'instances compared to the end %d' % ok_r.sum())
+        return dict(n=int(v.size), median=float(np.median(v)), p90=float(np.percentile(v, 90)), p99=float(np.percentile(v, 99)), max=float(v.max()))
+    ef, er = np.fmax(err, err_s), np.fmax(err_r, err_rs)          # per (step, instance): decision vector and node states together
+    d, dr = q(ef), q(er)
+    settled, settled_r = q(ef[SETTLED_FROM:]), q(er[SETTLED_FROM:])
+    over = lambda a: np.sum(np.where(np.isfinite(a), a, 0.0) > 1e-4, axis=1)          # per step: instances beyond the parity tolerance
+    of, orr = over(ef), over(er)
+    print('own path, 128 x 100, bench mode (tol_step 1e-5, start_mu 0.1) vs oracle:', d, 'from step %d on:' % SETTLED_FROM, settled, 'instances compared to the end %d' % ok.sum(), ctr)
+    print('own path, 128 x 100, reference criterion on the device vs oracle:       ', dr, 'from step %d on:' % SETTLED_FROM, settled_r, 'instances compared to the end %d' % ok_r.sum())
+    print('instances beyond 1e-4 per step, bench mode:         ', of.tolist())
+    print('instances beyond 1e-4 per step, reference criterion:', orr.tolist())
     assert ok.sum() >= 0.95 * ok.size and d['n'] >= 0.95 * err.size
     assert ctr['low_tried'] >= 0.8 * ctr['solves'] and ctr['step_rule'] >= 0.8 * ctr['solves'], ctr
-    # ---- the stated bound of the product's fast mode on its own path ----
-    assert d['median'] <= OWN_PATH_MEDIAN and d['p99'] <= OWN_PATH_P99 and d['max'] <= OWN_PATH_MAX, d
-    assert ds['p99'] <= OWN_PATH_P99 and ds['max'] <= OWN_PATH_MAX, ds
-    assert late['p99'] <= max(2.0 * early['p99'], OWN_PATH_MEDIAN), (early, late)          # no secular growth along the path
-    # ... and how it compares with two gap-criterion IPMs on their own paths (the floor of any own-path comparison)
-    assert d['p99'] <= 20.0 * max(dr['p99'], 1e-6), (d, dr)
+    # ---- the stated bounds of the fast mode on its own path (what was observed is in DESIGN.md section 4) ----
+    # (1) over all (instance, step) pairs: typical difference an order below the parity tolerance, nine in ten pairs within it
+    assert d['median'] <= 1e-5 and d['p90'] <= 1e-4, d
+    # (2) the paths part TRANSIENTLY after the first extension of the horizon (steps 5-30: a new polynomial enters the window, each side's SQP
+    #     finds the weakly determined new variables on its own path) and come together again: from step SETTLED_FROM on every pair is within the
+    #     parity tolerance, and nothing ever leaves the scale of the problem
+    assert settled['max'] <= 1e-4, settled
+    assert d['max'] <= 0.2, d
+    # (3) the transient is a property of two SQP paths, not of the termination rule: two GAP-CRITERION solvers (device with the rule off, oracle)
+    #     show the same picture, and the fast mode is no worse than that -- in how many instances leave the tolerance at any step, and in the tail
+    assert of.max() <= 1.5 * orr.max() + 3 and of.sum() <= 1.5 * orr.sum() + 10, (of.max(), orr.max(), of.sum(), orr.sum())
+    assert d['p99'] <= 2.0 * dr['p99'] + 1e-4 and d['max'] <= 2.0 * dr['max'] + 1e-4, (d, dr)
 
 
-OWN_PATH_MEDIAN, OWN_PATH_P99, OWN_PATH_MAX = 1e-4, 2e-3, 2e-2      # (placeholders until measured: see the print of the first GPU run)
+SETTLED_FROM = 45

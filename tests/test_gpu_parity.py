@@ -246,6 +246,7 @@ def test_device_resident_protocol_equals_host_driven_loop():
     B = 3
     ga = host.BatchMPC(cfg, B); ga.set_state_trajectory_warm_start(s0); ga.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
     gb = host.BatchMPC(cfg, B); gb.set_state_trajectory_warm_start(s0); gb.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
+    ga.enable_fast_termination(); gb.enable_fast_termination()      # the fused launch of ga then makes the lower-start attempts, gb's one-step launches do not
     ga.create_initial_run(s0, EE0); gb.create_initial_run(s0, EE0)
     o = OracleMPC(cfg); o.set_warmstart(s0); o.initial_run(s0, EE0)
     K = 7
@@ -277,7 +278,7 @@ def test_fused_kernel_equals_one_launch_per_phase():
         g = host.BatchMPC(cfg, B)
         g.set_state_trajectory_warm_start(states)
         g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
-        g.set_solver_step_rule(g.solver_step_rule()[0], 0.0)      # (the lower-start attempt belongs to the K-step launch alone: off on both sides)
+        g.set_solver_step_rule(host.FAST_TOL_STEP, 0.0)           # step rule on, no lower-start attempt (it belongs to the K-step launch alone: off on both sides)
         g.create_initial_run(states, ees)
         (g.rti_advance if fused else g.rti_advance_unfused)(0, 7)
         g.synchronize()
@@ -356,7 +357,7 @@ def test_statistics_log_line_format(tmp_path):
         g.print_stat_header(fh)
         g.print_stat_line(fh, 10, 1.25)
     lines = open(p).read().splitlines()
-    assert lines[0] == '-' * 150 and 'MPC Statistics' in lines[1] and lines[2] == 'Number of nodes: 20'
+    assert lines[0] == '-' * 150 and 'MPC Statistics' in lines[1] and lines[2].startswith('MPC started at: ') and lines[3] == 'Number of nodes: 20'
     row = lines[-1]
     assert len(row) == 150
     cols = [row[15 * i:15 * (i + 1)].strip() for i in range(10)]
