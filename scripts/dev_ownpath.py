@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 from oracle_py import OracleMPC, load_config
 from srbm_loader import host
 from bench import config_b_instance
-B, steps = 32, 60
+B, steps = int(os.environ.get('B', 32)), int(os.environ.get('STEPS', 60))
 cfg = load_config(); dt = cfg['integrator_dt']
 states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
 states, ees = np.array(states), np.array(ees)
@@ -40,3 +40,15 @@ for i in range(steps):
     print('step %2d n %d  median %.2e max %.2e (inst %d entry %d of %d)  statuses dev %s oracle %s  alpha dev %.3g oracle %.3g  box dev %s oracle %s  n>1e-4: %d' % (
         i, sz[0, 0], np.median(errs), errs.max(), wb, where[wb], sz[wb, 0], dict(zip(*np.unique(st, return_counts=True))), dict(zip(*np.unique(so, return_counts=True))),
         stats[wb, 0], os_['alpha'], g.knots(wb)['box'], os_['box'], (errs > 1e-4).sum()))
+    if errs.max() > 1e-3 and i > 40:
+        o = oracles[wb]; n = o.sizes()['n']
+        d = np.abs(x[wb, :n] - o.x())
+        idx = np.argsort(-d)[:6]
+        print('   worst entries', [(int(k), float(x[wb, k]), float(o.x()[k])) for k in idx])
+        kd = g.knots(wb)
+        for ee in range(4):
+            ko = o.knots(ee)
+            K = ko['K']
+            print('   foot', ee, 'K dev', kd['nk'][ee], 'oracle', K, 'times equal', np.array_equal(kd['times'][ee][:K], ko['times']), 'dev', kd['times'][ee][:kd['nk'][ee]].tolist(), 'kinds', kd['kinds'][ee][:kd['nk'][ee]].tolist())
+            print('        oracle times', list(ko['times']))
+        print('   sizes dev', sz[wb].tolist(), 'oracle', o.sizes())
