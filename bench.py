@@ -422,17 +422,17 @@ def main():
         rr = run_protocol(cfg, make_instance, B, False, False, args.warmup, args.steps, max(3, min(args.repeats, 5)))
         ref_stats = summary(rr, args.steps, 'Config B, same protocol, every solve to the reference criterion (srbm_set_solver_step_rule(0, 0): the library default)')
         del rr
-    # ---- BASELINE configs 4 and 5 at their per-GPU sizes, short runs of the same protocol (driver-visible numbers: VERDICT r3 item 4) ----
+    # ---- BASELINE configs 4 and 5 at their per-GPU sizes, the same protocol with the same --steps / --warmup / --repeats (driver-visible numbers: VERDICT r3 item 4) ----
     d_stats = e_stats = None
     if args.workload == 'B' and args.extra_workloads:
         cfg_d = host.load_config('a1_config_distr_rejection')
-        rd = run_protocol(cfg_d, config_d_instance, 512, False, FAST, 3, 10, 3)
-        d_stats = summary(rd, 10, 'Config D: 512 A1 SRBM MPC instances per GPU, N=50, dt=0.02, a1_config_distr_rejection.yaml values, push distribution on the '
+        rd = run_protocol(cfg_d, config_d_instance, 512, False, FAST, args.warmup, args.steps, args.repeats)
+        d_stats = summary(rd, args.steps, 'Config D: 512 A1 SRBM MPC instances per GPU, N=50, dt=0.02, a1_config_distr_rejection.yaml values, push distribution on the '
                                   'initial momentum (co-resident kernel set); not-solved solves belong to instances whose QPs the oracle finds infeasible too')
         del rd
         cfg_e = host.load_config('a1_configuration', num_nodes=40)
-        re_ = run_protocol(cfg_e, config_b_instance, 128, True, FAST, 3, 10, 3)
-        e_stats = summary(re_, 10, 'Config E (SRBM stand-in for the dead centroidal MPC): 128 instances per GPU, N=40, dt=0.05, LARGE-capacity build')
+        re_ = run_protocol(cfg_e, config_b_instance, 128, True, FAST, args.warmup, args.steps, args.repeats)
+        e_stats = summary(re_, args.steps, 'Config E (SRBM stand-in for the dead centroidal MPC): 128 instances per GPU, N=40, dt=0.05, LARGE-capacity build')
         del re_
 
     # ---- second segment (Config C): N=20 / dt=0.05 with the values of apps/a1_gait_opt_config.yaml, gait step every 5th iteration ----
