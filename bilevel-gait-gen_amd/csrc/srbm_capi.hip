@@ -758,7 +758,7 @@ int srbm_get_real_time_update_dev(srbm_batch* h, const double* state_dev, const 
 static int launch_fused(srbm_batch* h, int first_index, int steps, SrbmPlantArgs pl) {
     // (the lower-start attempt rests on the linearisation point being close to the new minimiser: true for the open-loop protocol, whose state IS
     //  node 1 of the plan; under a plant -- integration error every step, pushes -- it is repeated too often to pay: closed loop 62 k it/s with, 80 k without)
-    pl.tol_step = h->hp.tol_step; pl.start_mu = (pl.plant || pl.tol_step <= 0.0) ? 0.0 : h->hp.start_mu;
+    pl.tol_step = h->hp.tol_step; pl.start_mu = pl.plant ? 0.0 : h->hp.start_mu;
     HIPCHK(hipSetDevice(h->device));
     if (upload_params(h)) return -1;
     if (steps == 0) return 0;

@@ -342,6 +342,11 @@ class BatchMPC:
         """opt into the step rule (and, for srbm_rti_advance, the lower-start attempt) at the values the bench line is taken with"""
         self.set_solver_step_rule(FAST_TOL_STEP, start_mu)
 
+    def enable_lower_start(self, start_mu=FAST_START_MU):
+        """the lower starting point alone: every solve still ends by the reference's gap criterion (tol_step 0), srbm_rti_advance first attempts it
+        from the linearisation point"""
+        self.set_solver_step_rule(0.0, start_mu)
+
     def solve_flags(self):
         """per instance, of the LAST solve: bit 0 ended through the step rule, bit 1 began with a lower-start attempt, bit 2 the attempt was repeated"""
         f = np.zeros(self.batch, np.int32)

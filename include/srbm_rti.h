@@ -70,13 +70,15 @@ int srbm_set_solver_tolerances(srbm_batch* h, double tol_gap_abs, double tol_gap
  *     that ended through the rule is flagged (srbm_get_solve_flags bit 0), residuals / gap / QP cost reported for it are re-evaluated at the
  *     returned iterate, and srbm_gait_compute_sensitivity / _gradient REFUSE it (error return, not a silent valid = 0) -- srbm_gait_rti_advance
  *     runs the one solve it differentiates at the gap criterion by itself, a caller that drives that protocol passes tol_step = 0 first.
- *   start_mu > 0 (needs tol_step > 0): every solve is first ATTEMPTED from the linearisation point (the shifted solution of the previous RTI
- *     step) with slacks h - G u and perfectly centred multipliers lambda = start_mu / s -- five to six decades further down the central path
- *     than Clarabel's starting point -- and repeated from the standard point unless the attempt ends through the step rule.  Honoured by the
- *     device-resident open-loop launch srbm_rti_advance ONLY (there a repeated attempt of one instance is averaged over its K steps and the
- *     state is node 1 of the plan); IGNORED by srbm_get_real_time_update[_dev], srbm_rti_advance_unfused, srbm_create_initial_run (one-step
- *     launches wait for the slowest instance every time), by srbm_closed_loop_advance (integration error and pushes make the attempts fail)
- *     and by srbm_gait_rti_advance (its candidates belong to other contact schedules).
+ *   start_mu > 0: every solve is first ATTEMPTED from the linearisation point (the shifted solution of the previous RTI step) with slacks
+ *     h - G u and perfectly centred multipliers lambda = start_mu / s -- five to six decades further down the central path than Clarabel's
+ *     starting point -- with an iteration budget, and repeated from the standard point unless the attempt ends Solved (through the step rule
+ *     or, with tol_step = 0, through the gap criterion itself: (0, start_mu) keeps the reference's TERMINATION criterion for every solve and only
+ *     changes where the iteration starts).  Honoured by the device-resident open-loop launch srbm_rti_advance ONLY (there a repeated attempt of
+ *     one instance is averaged over its K steps and the state is node 1 of the plan); IGNORED by srbm_get_real_time_update[_dev],
+ *     srbm_rti_advance_unfused, srbm_create_initial_run (one-step launches wait for the slowest instance every time), by
+ *     srbm_closed_loop_advance (integration error and pushes make the attempts fail) and by srbm_gait_rti_advance (its candidates belong to
+ *     other contact schedules).
  * SRBM_FAST_TOL_STEP / SRBM_FAST_START_MU are the values bench.py opts into for its headline line (1e-4 relative primal accuracy is the bar of
  * the path; parity of that mode: tests/test_gpu_resync.py); the same line carries the run at (0, 0). */
 #define SRBM_FAST_TOL_STEP 1e-5

@@ -99,7 +99,7 @@ def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None, step_rule=Tr
                           for b, o in enumerate(oracles)]).reshape(B, 12)
         if fused:
             g.rti_advance(i, 1); g.synchronize()
-            if step_rule:       # every solve of this launch began with an attempt (installing a trajectory resets the back-off)
+            if g.solver_step_rule()[1] > 0:       # every solve of this launch began with an attempt (installing a trajectory resets the back-off)
                 fl = g.solve_flags()
                 assert np.all(fl & 2), (i, np.nonzero((fl & 2) == 0)[0][:8])
         else:
@@ -237,7 +237,7 @@ def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None, step_rule=Tr
     assert alive.sum() >= (0.97 * B if min_alive is None else min_alive), alive.sum()
     ctr = g.solver_counters()
     assert ctr['solves'] == B * steps
-    if fused and step_rule:                    # the test cannot silently run without attempts
+    if fused and g.solver_step_rule()[1] > 0:  # the test cannot silently run without attempts
         assert ctr['low_tried'] >= 0.8 * ctr['solves'], ctr
     assert n_inacc <= max(2, total // 500), (n_inacc, total)          # (observed: 0-1 of 5 120 solves)
     return dict(inacc=n_inacc, x_by_step=x_by_step, counters=ctr, alive=int(alive.sum()), sizes=seen_sizes, td_steps=seen_td, worst=worst, exact_status=exact_status, total=total, z_unique=n_unique, certified=n_cert)
@@ -312,6 +312,21 @@ def test_config_b_at_the_reference_criterion_entrywise():
     r = resync_protocol(cfg, states, ees, steps=10, step_rule=False)
     assert r['worst']['A'] <= 1e-12 and r['worst']['x'] < REL_TOL and r['worst']['z'] < REL_TOL and r['worst']['dual_obj'] <= 1e-6
     print('resync parity at the reference criterion, 64 x 10: worst', r['worst'])
+
+
+def test_config_b_reference_criterion_with_lower_start_through_the_fused_launch():
+    """srbm_set_solver_step_rule(0, 0.1): every solve ENDS by the reference's gap criterion, the fused launch first attempts it from the
+    linearisation point (the mode of bench.py's `reference_criterion_lower_start` object).  Same strict bounds as the (0, 0) run above -- dual
+    objective to 1e-6 of its value, stationarity 1e-7 -- on 128 instances x 12 steps, every solve began with an attempt"""
+    cfg = load_config()
+    B = 128
+    states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees)
+    r = resync_protocol(cfg, states, ees, steps=12, step_rule=False, fused=True, start_mu=host.FAST_START_MU, min_alive=B - 3)
+    c = r['counters']
+    print('resync parity, reference criterion + lower start through the fused launch, 128 x 12: worst', r['worst'], c)
+    assert r['worst']['A'] <= 1e-12 and r['worst']['x'] < REL_TOL and r['worst']['z'] < REL_TOL and r['worst']['dual_obj'] <= 1e-6
+    assert c['step_rule'] == 0 and c['low_tried'] == c['solves'] and c['low_failed'] <= 0.25 * c['solves'], c
 
 
 def test_config_c_values_at_n20_entrywise():
