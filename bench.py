@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (public spec; the CDNA guide lists no fp64 row)
 MFMA_FLOP = 2048.0           # one v_mfma_f64_16x16x4_f64: 16 x 16 x 4 multiply-adds
 BATCH_PER_GPU = 256
-PROFILE_ROUND = 'r03'
+PROFILE_ROUND = 'r04'
 
 
 # ---------- helpers shared with the CPU (gloo) tests of the sharding logic ----------

