@@ -10,6 +10,9 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 s0 = np.array(cfg['srb_init'], float)
 ee = np.array([[0.2, 0.2, 0], [0.2, -0.2, 0], [-0.2, 0.2, 0], [-0.2, -0.2, 0]], float)
 gb = host.BatchMPC(cfg, B); gb.set_state_trajectory_warm_start(s0)
+if os.environ.get('PROF_MODE', 'fast') == 'fast':
+    gb.enable_fast_termination()           # the mode bench.py times (PROF_MODE=ref: the reference criterion)
+print('solver settings', gb.solver_step_rule())
 gb.create_initial_run(s0, ee)
 gb.rti_advance(0, 4); gb.synchronize()
 out = np.zeros(16)

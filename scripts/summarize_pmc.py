@@ -87,7 +87,7 @@ def counters(sub):
 
 F, W, S1, S2 = counters('pmc_fetch'), counters('pmc_write'), counters('pmc_sq1'), counters('pmc_sq2')
 summ = {'kernel': KERNEL, 'round': rnd, 'kernel_source_sha': bench.kernel_source_sha(), 'steps_per_launch': steps, 'timed_launches': repeats,
-        'command': 'rocprofv3 --pmc <one pass per counter group, no other tracing> -- python3 bench.py --no-cpu-baseline --gait-steps 0 --closed-loop-steps 0 --wbc-ticks 0',
+        'command': 'rocprofv3 --pmc <one pass per counter group, no other tracing> -- python3 bench.py --no-cpu-baseline --no-reference-criterion --extra-workloads 0 --gait-steps 0 --closed-loop-steps 0 --wbc-ticks 0',
         'launch_described': 'the median region of the timed five (index %d): counters, duration and the bench line all refer to it' % MED_IDX,
         'kernel_trace_ms_per_launch': ms[MED_IDX], 'hip_event_ms_per_launch_same_run': pb['roofline']['avg_launch_ms'],
         'raw_counters_per_launch': {**F, **W, **S1, **S2}}
