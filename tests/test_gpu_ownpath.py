@@ -29,7 +29,7 @@ def relerr(a, b):
     return np.abs(a - b).max() / max(1.0, np.abs(b).max())
 
 
-def own_path_run(fast, B=128, steps=100):
+def own_path_run(fast, B=128, steps=100, mode=None):
     cfg = load_config()
     dt = cfg['integrator_dt']
     nx = (cfg['num_nodes'] + 1) * 12
@@ -38,7 +38,9 @@ def own_path_run(fast, B=128, steps=100):
     g = host.BatchMPC(cfg, B)
     g.set_state_trajectory_warm_start(states)
     g.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
-    if fast:
+    if mode is not None:
+        g.set_solver_step_rule(*mode)
+    elif fast:
         g.enable_fast_termination()
     oracles = []
     for b in range(B):
