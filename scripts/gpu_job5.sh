@@ -1,7 +1,11 @@
 #!/bin/bash
 D=gpurun_out/r4
 mkdir -p $D
-L=bilevel-gait-gen_amd
-for wl in D B; do
-  AB_WORKLOAD=$wl AB_STEP=1e-5 AB_MU=0.1 AB_WINDOWS=1 timeout -k 10 400 python scripts/dev_ab.py $L/ab/libr03.so $L/libsrbm_rti.so $L/ab/libr03.so $L/libsrbm_rti.so 2>&1 | grep windows | sed "s/^/$wl: /" | cut -c1-200
-done
+timeout -k 10 600 python -m pytest tests/test_gpu_gait.py tests/test_cpp_facade.py tests/test_gpu_bench.py -m gpu -x -q > $D/gait_tests.log 2>&1
+tail -4 $D/gait_tests.log
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-reference-criterion --extra-workloads 0 --closed-loop-steps 0 --wbc-ticks 0 > $D/bench_gait.json 2> $D/bench_gait.err
+python - <<PY
+import json
+d=json.loads([l for l in open('$D/bench_gait.json') if l.startswith('{')][0])
+print('value', d['value'], 'gait', d['gait'])
+PY
