@@ -379,10 +379,26 @@ __global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_solve(int n, const do
     int nreg = 0;
     dn_load_packed(T, M, n);
     dn_cholesky(T, M, n, panel, &nreg);
-    chol_invert_diag_blocks(M, n);
+    chol_invert_diag_blocks(M, n, panel);
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-    dn_trtri(M, n);
-    dn_scale_inverse_rows(M, n, panel);
+#ifdef DN_TRTRI_STAMPS
+    {   // diagnostic: dn_trtri taken apart
+        const int wid = dn_wave_id();
+        const int T = (n + DN_TILE - 1) / DN_TILE;
+        dn_v4 Xa[DN_MAXT];
+        const int ja = dn_trtri_owned_column(wid, 0, T);
+        if (ja >= 0) dn_trtri_column<DN_MAXT>(M, n, T, ja, Xa);
+        const long long ta = (long long)__builtin_amdgcn_s_memtime();
+        __syncthreads();
+        const long long tb = (long long)__builtin_amdgcn_s_memtime();
+        if (ja >= 0) dn_trtri_store<DN_MAXT>(M, n, T, ja, Xa, panel);
+        __syncthreads();
+        const long long tc = (long long)__builtin_amdgcn_s_memtime();
+        if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) printf("trtri stamps n %d wave %d column %d: columns %lld barrier %lld store %lld\n", n, wid, ja, ta - t0, tb - ta, tc - tb);
+    }
+#else
+    dn_trtri(M, n, panel);
+#endif
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
     dn_solve_inv(0, n, (int)(xv - dbg_smem2), (int)(tv - dbg_smem2), -1, 0, 0
 #ifdef SRBM_M_GLOBAL
@@ -433,9 +449,8 @@ __global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_solve_mapped(int n, i
     int nreg = 0;
     dn_load_packed(T, M, nc, imap);
     dn_cholesky(T, M, nc, panel, &nreg);
-    chol_invert_diag_blocks(M, nc);
-    dn_trtri(M, nc);
-    dn_scale_inverse_rows(M, nc, panel);
+    chol_invert_diag_blocks(M, nc, panel);
+    dn_trtri(M, nc, panel);
     dn_solve_inv(0, nc, (int)(xv - dbg_smem3), (int)(tv - dbg_smem3), (int)(reinterpret_cast<double*>(imap) - dbg_smem3), (int)(xc - dbg_smem3), 0
 #ifdef SRBM_M_GLOBAL
                  , M
