@@ -434,7 +434,7 @@ def main():
         cfg_d = host.load_config('a1_config_distr_rejection')
         rd = run_protocol(cfg_d, config_d_instance, 512, False, FAST, args.warmup, args.steps, args.repeats)
         d_stats = summary(rd, args.steps, 'Config D: 512 A1 SRBM MPC instances per GPU, N=50, dt=0.02, a1_config_distr_rejection.yaml values, push distribution on the '
-                                  'initial momentum (co-resident kernel set); not-solved solves belong to instances whose QPs the oracle finds infeasible too')
+                                  'initial momentum; not-solved solves belong to instances whose QPs the oracle finds infeasible too')
         del rd
         cfg_e = host.load_config('a1_configuration', num_nodes=40)
         re_ = run_protocol(cfg_e, config_b_instance, 128, True, FAST, args.warmup, args.steps, args.repeats)

@@ -53,7 +53,7 @@ struct srbm_batch {
     bool owns_stream = true;
     size_t k3_lds = 0;
     // kernel set: 0 = standard (512 threads, normal matrix in LDS, one instance per CU), 1 = co-resident (srbm_co.h).  Chosen by the batch size
-    // at creation (more instances than CUs -> co-resident), srbm_set_kernel_set overrides.  dp_co: the parameters with the co-resident LDS size
+    // at creation (set 0; srbm_set_kernel_set chooses).  dp_co: the parameters with the co-resident LDS size
     int kernel_set = 0, n_cu = 0;
     bool co_available = false;
     SrbmParams* dp_co = nullptr;
@@ -574,7 +574,10 @@ static int alloc_batch(srbm_batch* h, hipStream_t borrowed_stream) {
 #endif
 #ifndef SRBM_LARGE
     {
-        // the co-resident set: available when the horizon's working set fits half a CU; chosen when the batch has more instances than the GPU has CUs
+        // the co-resident set: available when the horizon's working set fits half a CU; chosen by srbm_set_kernel_set only.  (Rounds 2-3 created
+        // batches beyond the CU count on it: 17 % faster then.  With round 4's dense phase a co-resident workgroup takes 2.1 x a standard one, so
+        // two of them side by side lose to two standard rounds: Config D 7.42 vs 7.02 ms per step, the 2 560 candidates of a gait line search
+        // 8.00 vs 7.70 ms per step of the gait segment.)
         int n_cu = 0;
         HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
         h->n_cu = n_cu;
@@ -582,7 +585,7 @@ static int alloc_batch(srbm_batch* h, hipStream_t borrowed_stream) {
         if (co_rc == -1) return fail(std::string("srbm_co_configure: ") + hipGetErrorString(hipGetLastError()));
         h->co_available = co_rc == 0;
         if (h->co_available) HIPCHK(hipMalloc(&h->dp_co, sizeof(SrbmParams)));
-        h->kernel_set = (h->co_available && n_cu > 0 && h->batch > n_cu) ? 1 : 0;
+        h->kernel_set = 0;
     }
 #endif
     h->params_dirty = true;

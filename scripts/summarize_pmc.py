@@ -132,7 +132,7 @@ def kernel_stats(sub, out_name, title, bench_json=None):
             fh.write('%s,%s,%s,%s,%s,%s,%s\n' % (r['Name'].split('(')[0], r['Calls'], r['TotalDurationNs'], r['AverageNs'], r['Percentage'], r['MinNs'], r['MaxNs']))
 
 
-kernel_stats('trace_D', 'D_kernel_stats.csv', 'rocprofv3 --kernel-trace --stats -- python3 bench.py --workload D --no-cpu-baseline --closed-loop-steps 0 (512 instances, N = 50: co-resident kernel set)', 'bench_D_under_rocprof.json')
+kernel_stats('trace_D', 'D_kernel_stats.csv', 'rocprofv3 --kernel-trace --stats -- python3 bench.py --workload D --no-cpu-baseline --closed-loop-steps 0 (512 instances, N = 50: standard kernel set, two rounds of 256 workgroups)', 'bench_D_under_rocprof.json')
 kernel_stats('trace_E', 'E_kernel_stats.csv', 'rocprofv3 --kernel-trace --stats -- python3 bench.py --workload E --no-cpu-baseline --closed-loop-steps 0 (128 instances, N = 40: LARGE build)', 'bench_E_under_rocprof.json')
 kernel_stats('trace_gait', 'gait_kernel_stats.csv', 'rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --closed-loop-steps 0 --wbc-ticks 0 (Config B region + the gait segment: 30 steps, 6 gait steps, 6 line searches)', 'bench_gait_under_rocprof.json')
 
@@ -154,7 +154,7 @@ cd = counters_of('pmc_D_sq1', 'srbm_rti_fused')
 if cd:
     c, nd = cd
     gui = c.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
-    extra['config_D_co_resident'] = {'kernel': 'srbm_co::srbm_rti_fused_long (512 instances on 256 CUs)', 'dispatches_averaged': nd, 'raw_counters_per_launch': c,
+    extra['config_D'] = {'kernel': 'srbm_rti_fused_long (512 instances on 256 CUs, standard kernel set since round 4: two rounds)', 'dispatches_averaged': nd, 'raw_counters_per_launch': c,
         'waves_launched_per_launch': c.get('SQ_WAVES'),
         'occupancy_waves_per_cu': 4.0 * c['SQ_WAVE_CYCLES'] / (gui * 256) if gui and 'SQ_WAVE_CYCLES' in c else None,
         'mfma_busy_frac': c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui * 256 * 4) if gui else None,

@@ -88,5 +88,7 @@ def test_co_resident_set_against_the_oracle_and_the_default_selection():
             xo = o.qp_x()
             worst = max(worst, np.abs(xr[b, :len(xo)] - xo).max() / max(1.0, np.abs(xo).max()))
     assert worst < 1e-4, worst
-    big = host.BatchMPC(cfg, 300)                      # more instances than the 256 CUs of an MI355X: created on the co-resident set
+    big = host.BatchMPC(cfg, 300)                      # more instances than the 256 CUs of an MI355X: still created on the standard set (round 4)
+    assert big.kernel_set() == 0
+    big.set_kernel_set(1)                              # ... the co-resident set is there on request
     assert big.kernel_set() == 1
