@@ -46,6 +46,8 @@ def test_bench_line_under_torchrun_with_the_collective_path():
         assert k in cb, k
     assert cb['kind'] == 'port' and cb['cores'] == 1 and cb['value'] > 10
     assert d['gait']['err_bits_all_steps'] == 0 and d['closed_loop']['plant_finite'] and d['wbc']['finite']
+    ss = d['steady_state']        # the headline's protocol continued past the transient after the cold start (bench.py --steady-from)
+    assert ss['first_step'] == 125 and ss['all_solved_after'] and len(ss['region_ms']) == 2 and ss['value'] > 1e4
 
 
 def run_bench(*args):
