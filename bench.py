@@ -406,7 +406,7 @@ def main():
         ts, mu = m.solver_step_rule()
         return {'workload': label, 'value': r['n_inst'] * steps / el, 'unit': 'it/s', 'ms_per_step': 1e3 * el / steps, 'steps': steps, 'repeats': len(r['region_s']),
                 'region_ms': [1e3 * v for v in r['region_s']], 'batch_per_gpu': r['hi'] - r['lo'], 'global_batch': r['n_inst'], 'num_nodes': m.N,
-                'kernel_set': m.kernel_set(), 'large_build': bool(m.large), 'records_gathered': int(r['allrec'].shape[0]),
+                'large_build': bool(m.large), 'records_gathered': int(r['allrec'].shape[0]),
                 'mean_ipm_iterations': r['mean_iters'], 'timed_solves': int(q_[1]), 'not_solved_in_timed_solves': int(q_[2]),
                 'max_iter_in_timed_solves': int(q_[3]), 'err_bits_all_timed_steps': int(q_[0]), 'all_solved': bool(q_[2] == 0 and q_[0] == 0),
                 'instances_with_a_solve_not_solved_rank0': [int(r['lo'] + b) for b in np.nonzero(r['acc'][:, 2])[0][:64]],
@@ -688,7 +688,7 @@ def main():
                                     'distribution on the initial momentum, 10 cold-start solves then open-loop RTI steps' % B) if args.workload == 'D' else
                                    ('Config E (SRBM stand-in for the dead centroidal MPC, no reference parity beyond the SRBM restatement): %d instances per GPU, '
                                     'N=40, dt=0.05, a1_configuration.yaml values, LARGE-capacity build (normal matrix in L2)' % B),
-                       'batch_per_gpu': B, 'global_batch': n_inst, 'num_nodes': cfg['num_nodes'], 'kernel_set': mpc.kernel_set(), 'parallelism': 'instances sharded x%d' % world,
+                       'batch_per_gpu': B, 'global_batch': n_inst, 'num_nodes': cfg['num_nodes'], 'parallelism': 'instances sharded x%d' % world,
                        'records_gathered': int(allrec.shape[0]), 'record_doubles': LD,
                        'all_solved': bool(q[2] == 0 and q[0] == 0), 'statuses_last_step': {int(k): int(v) for k, v in zip(*np.unique(status_all, return_counts=True))},
                        'timed_solves': int(q[1]), 'not_solved_in_timed_solves': int(q[2]), 'max_iter_in_timed_solves': int(q[3]),

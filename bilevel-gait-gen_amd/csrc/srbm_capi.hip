@@ -15,7 +15,6 @@
 #include "srbm_wbc.hiph"
 #include "../../include/srbm_rti.h"
 #ifndef SRBM_LARGE
-#include "srbm_co.h"           // the co-resident kernel set (two instances per CU) for batches beyond the CU count
 #endif
 
 #ifdef SRBM_LARGE
@@ -52,12 +51,7 @@ struct srbm_batch {
     hipStream_t stream = nullptr;
     bool owns_stream = true;
     size_t k3_lds = 0;
-    // kernel set: 0 = standard (512 threads, normal matrix in LDS, one instance per CU), 1 = co-resident (srbm_co.h).  Chosen by the batch size
-    // at creation (set 0; srbm_set_kernel_set chooses).  dp_co: the parameters with the co-resident LDS size
-    int kernel_set = 0, n_cu = 0;
-    bool co_available = false;
-    SrbmParams* dp_co = nullptr;
-    size_t k3_lds_co = 0;
+    int n_cu = 0;
     bool params_dirty = true;
     // optional HIP-event timing of the dominant kernel (srbm_k3_ipm) on the launch stream
     bool timing = false;
@@ -294,11 +288,6 @@ static int upload_params(srbm_batch* h) {
     h->hp.q_diag = 1;
     for (int i = 0; i < 144; i++) if (i % 13 != 0 && (h->hp.Q[i] != 0.0 || h->hp.Phi[i] != 0.0)) h->hp.q_diag = 0;
     HIPCHK(hipMemcpyAsync(h->dp, &h->hp, sizeof(SrbmParams), hipMemcpyHostToDevice, h->stream));
-    if (h->dp_co) {
-        SrbmParams pc = h->hp;
-        pc.lds_doubles = (int)(h->k3_lds_co / sizeof(double));
-        HIPCHK(hipMemcpyAsync(h->dp_co, &pc, sizeof(SrbmParams), hipMemcpyHostToDevice, h->stream));     // (pageable source: staged before the call returns)
-    }
     h->params_dirty = false;
     return 0;
 }
@@ -320,16 +309,6 @@ static int launch_step(srbm_batch* h, bool exact = false) {
     const double tol_step = exact ? 0.0 : h->hp.tol_step, start_mu = 0.0;
     h->last_tol_step = tol_step;
     const int B = h->batch;
-#ifndef SRBM_LARGE
-    if (h->kernel_set == 1) {
-        const bool tmc = h->timing && h->ev_used < h->ev_start.size();
-        if (srbm_co_launch_step(h->stream, h->dp_co, h->insts, h->works, h->d_state, h->d_time, h->d_ee, B, h->hp.N, h->k3_lds_co, tol_step, start_mu,
-                                tmc ? h->ev_start[h->ev_used] : nullptr, tmc ? h->ev_stop[h->ev_used] : nullptr))
-            return fail("launch of the co-resident kernel set failed");
-        if (tmc) { h->ev_steps[h->ev_used] = 1; h->ev_used++; }
-        return 0;
-    }
-#endif
     hipLaunchKernelGGL(srbm_k1_assemble, dim3(B), dim3(K1_THREADS), SRBM_DYN_LDS(K1Shared), h->stream, h->dp, h->insts, h->works, h->d_state, h->d_time, h->d_ee);
     hipLaunchKernelGGL(srbm_k2_condense, dim3(B), dim3(K2_THREADS), SRBM_DYN_LDS(K2Shared), h->stream, h->dp, h->insts, h->works);
     const bool tm = h->timing && h->ev_used < h->ev_start.size();
@@ -381,24 +360,7 @@ __global__ __launch_bounds__(DN_THREADS) void srbm_k_debug_solve(int n, const do
     dn_cholesky(T, M, n, panel, &nreg);
     chol_invert_diag_blocks(M, n, panel);
     const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-#ifdef DN_TRTRI_STAMPS
-    {   // diagnostic: dn_trtri taken apart
-        const int wid = dn_wave_id();
-        const int T = (n + DN_TILE - 1) / DN_TILE;
-        dn_v4 Xa[DN_MAXT];
-        const int ja = dn_trtri_owned_column(wid, 0, T);
-        if (ja >= 0) dn_trtri_column<DN_MAXT>(M, n, T, ja, Xa);
-        const long long ta = (long long)__builtin_amdgcn_s_memtime();
-        __syncthreads();
-        const long long tb = (long long)__builtin_amdgcn_s_memtime();
-        if (ja >= 0) dn_trtri_store<DN_MAXT>(M, n, T, ja, Xa, panel);
-        __syncthreads();
-        const long long tc = (long long)__builtin_amdgcn_s_memtime();
-        if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) printf("trtri stamps n %d wave %d column %d: columns %lld barrier %lld store %lld\n", n, wid, ja, ta - t0, tb - ta, tc - tb);
-    }
-#else
     dn_trtri(M, n, panel);
-#endif
     const long long t1 = (long long)__builtin_amdgcn_s_memtime();
     dn_solve_inv(0, n, (int)(xv - dbg_smem2), (int)(tv - dbg_smem2), -1, 0, 0
 #ifdef SRBM_M_GLOBAL
@@ -537,7 +499,7 @@ static void free_batch(srbm_batch* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    (void)hipFree(h->dp); (void)hipFree(h->dp_co); (void)hipFree(h->insts); (void)hipFree(h->works);
+    (void)hipFree(h->dp); (void)hipFree(h->insts); (void)hipFree(h->works);
     (void)hipFree(h->d_state); (void)hipFree(h->d_time); (void)hipFree(h->d_ee);
     (void)hipFree(h->d_plant); (void)hipFree(h->d_push_time); (void)hipFree(h->d_push_impulse);
     (void)hipFree(h->d_scratch); (void)hipFree(h->d_wbc); (void)hipHostFree(h->h_stage);
@@ -572,22 +534,7 @@ static int alloc_batch(srbm_batch* h, hipStream_t borrowed_stream) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k2_condense), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(K2Shared)));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k4_update), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(K4Shared)));
 #endif
-#ifndef SRBM_LARGE
-    {
-        // the co-resident set: available when the horizon's working set fits half a CU; chosen by srbm_set_kernel_set only.  (Rounds 2-3 created
-        // batches beyond the CU count on it: 17 % faster then.  With round 4's dense phase a co-resident workgroup takes 2.1 x a standard one, so
-        // two of them side by side lose to two standard rounds: Config D 7.42 vs 7.02 ms per step, the 2 560 candidates of a gait line search
-        // 8.00 vs 7.70 ms per step of the gait segment.)
-        int n_cu = 0;
-        HIPCHK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
-        h->n_cu = n_cu;
-        const int co_rc = srbm_co_configure(h->hp.N, &h->k3_lds_co);     // 0 ok, -2 this horizon does not fit half a CU (stay on set 0), -1 a HIP error
-        if (co_rc == -1) return fail(std::string("srbm_co_configure: ") + hipGetErrorString(hipGetLastError()));
-        h->co_available = co_rc == 0;
-        if (h->co_available) HIPCHK(hipMalloc(&h->dp_co, sizeof(SrbmParams)));
-        h->kernel_set = 0;
-    }
-#endif
+    HIPCHK(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
     h->params_dirty = true;
     return 0;
 }
@@ -643,7 +590,6 @@ int srbm_batch_clone(const srbm_batch* src, srbm_batch** out) {
     h->batch = src->batch; h->device = src->device; h->hp = src->hp; h->push_set = src->push_set; h->last_tol_step = src->last_tol_step;
     auto bail = [&]() { free_batch(h); return -1; };
     if (alloc_batch(h, nullptr)) return bail();
-    h->kernel_set = src->kernel_set;
     const size_t B = h->batch;
     auto cp = [&](void* d, const void* s_, size_t n) { return hipMemcpyAsync(d, s_, n, hipMemcpyDeviceToDevice, h->stream) == hipSuccess; };
     bool ok = cp(h->insts, src->insts, sizeof(SrbmInst) * B) && cp(h->works, src->works, sizeof(SrbmWork) * B) &&
@@ -714,15 +660,6 @@ int srbm_set_solver_step_rule(srbm_batch* h, double tol_step, double start_mu) {
     h->params_dirty = true;
     return 0;
 }
-int srbm_set_kernel_set(srbm_batch* h, int which) {
-    if (!h || which < 0 || which > 1) return fail("bad arguments");
-    if (which == 1 && !h->co_available) return fail("srbm_set_kernel_set: the co-resident kernel set is not available for this build / horizon");
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->kernel_set = which;
-    return 0;
-}
-int srbm_get_kernel_set(const srbm_batch* h) { return h ? h->kernel_set : -1; }
 int srbm_get_solver_step_rule(const srbm_batch* h, double* tol_step, double* start_mu) {
     if (!h || !tol_step || !start_mu) return fail("bad arguments");
     *tol_step = h->hp.tol_step; *start_mu = h->hp.start_mu;
@@ -784,12 +721,6 @@ static int launch_fused(srbm_batch* h, int first_index, int steps, SrbmPlantArgs
     // one launch for all steps (double time = i*info.integrator_dt, gait_opt_playground.cpp:84, is formed on the device)
     const bool tm = h->timing && h->ev_used < h->ev_start.size();
     if (tm) HIPCHK(hipEventRecord(h->ev_start[h->ev_used], h->stream));
-#ifndef SRBM_LARGE
-    if (h->kernel_set == 1) {
-        if (srbm_co_launch_fused(h->stream, h->dp_co, h->insts, h->works, first_index, steps, h->d_state, h->d_time, h->d_ee, pl, h->batch, h->hp.N, h->k3_lds_co))
-            return fail("launch of the co-resident kernel set failed");
-    } else
-#endif
     if (h->hp.N <= K3_SHORT_N)
         hipLaunchKernelGGL(srbm_rti_fused, dim3(h->batch), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works, first_index, steps,
                            h->d_state, h->d_time, h->d_ee, pl);

@@ -12,9 +12,8 @@
 
 #define SRBM_NEE 4
 /* Where the packed normal matrix of the IPM lives: LDS (standard build: one workgroup of 512 threads per CU) or the work record in global
-   memory / L2 (SRBM_M_GLOBAL: the LARGE capacities, whose matrix does not fit the LDS, and the CO-RESIDENT kernel set SRBM_CO -- 256 threads and
-   <= 80 KB of LDS per workgroup, so that TWO instances share a CU and fill each other's latency gaps when the batch exceeds the CU count) */
-#if defined(SRBM_LARGE) || defined(SRBM_CO)
+   memory / L2 (SRBM_M_GLOBAL: the LARGE capacities, whose matrix does not fit the LDS) */
+#if defined(SRBM_LARGE)
 #define SRBM_M_GLOBAL 1
 #endif
 #define SRBM_KMAX 32          /* knots per foot inside the horizon window */
@@ -63,7 +62,7 @@ typedef struct SrbmParams {
     /* (host-side record of srbm_set_solver_step_rule; the kernels receive the two values as launch arguments)  tol_step > 0 ends a solve as soon as the affine (predictor) Newton step -- the distance to the KKT point of
        the QP as the factor at hand sees it -- is below tol_step * max(1, |u|_inf): the iterate then takes that step and the solve is over;
        start_mu > 0 (fused open-loop launches only): every solve is first attempted from the LINEARISATION POINT with slacks h - G u and centred
-       multipliers lambda = start_mu / s (K3_LOW_MODE 1, the compiled default; mode 0 = Clarabel's point with scaled multipliers is an A/B switch).
+       multipliers lambda = start_mu / s.
        Both are 0 in a new batch: the reference's gap criterion (include/srbm_rti.h, srbm_set_solver_step_rule) */
     double tol_step, start_mu;
     double legs[SRBM_NEE][4][3];    /* leg geometry for the IK of row f3 (srbm_ik.hiph): joint origins hip / thigh / calf / foot */
@@ -90,7 +89,7 @@ typedef struct SrbmInst {
     double acc_mfma;                              /* v_mfma_f64_16x16x4_f64 instructions EXECUTED (per wave) by the condensing and IPM phases: the executed-flop side of the roofline */
     int err_acc, n_solves, n_not_solved, n_maxiter;       /* n_not_solved: status not in {Solved, SolvedInacc}; n_maxiter: of those, MaxIter */
     int low_streak, last_rule;                            /* last_rule: 1 if the LAST solve ended through the step rule (its duals are then not at the reference's gap tolerance: the
-                                                             gait gradient is marked invalid); low_streak: consecutive failed attempts: the back-off doubles with each (K3_LOW_BACKOFF << streak, at most 48 solves) */
+                                                             gait gradient is marked invalid); low_streak: consecutive failed attempts: no back-off after the first failure of a streak, K3_LOW_BACKOFF << (streak - 1) solves (at most 48) from the second on */
     int last_low, pad_low;                                /* last solve: bit 0 began with a lower-start attempt, bit 1 the attempt was repeated from the standard start */
     int low_skip, n_low_tried, n_low_failed, n_step_rule; /* lower-start attempts (srbm_k3_ipm.hiph): solves left that skip the attempt, attempts, attempts repeated
                                                              from the standard start; solves ended by the step rule */
@@ -144,10 +143,13 @@ typedef struct SrbmWork {
     double x[SRBM_NXMAX];                         /* prev_qp_sol after the line search */
     double z[SRBM_MMAX];                          /* dual vector in the reference's row order */
     double s[SRBM_MMAX];
-    double Mg[SRBM_HPACK];                        /* SRBM_M_GLOBAL kernels: the normal matrix / its factor / the inverse of the factor of the IPM (in LDS otherwise) */
+#ifdef SRBM_M_GLOBAL
+    double Mg[SRBM_HPACK];                        /* the normal matrix / its factor / the inverse of the factor of the IPM (in LDS otherwise); followed by Ms: the one-block-ahead
+                                                     operand prefetch of dn_trtri_column reads up to 15 doubles past the packed matrix (values masked), which must stay inside the record */
+#endif
     double Ms[SRBM_HPACK];                        /* gait step: H + G' diag(lambda/s) G of the last solution (srbm_k3_normal_matrix) */
     double w0[SRBM_MIMAX];                        /* IPM: unit weight of the row/cost-scaled problem, e_r^2 / c (kernel 3 scratch) */
-    double hrow_g[SRBM_MIMAX];                    /* IPM: right-hand sides of the inequality rows (co-resident set: read from here instead of held in registers) */
+    double hrow_g[SRBM_MIMAX];                    /* IPM: right-hand sides of the inequality rows (large build: read from here instead of held in registers) */
     double prof2[64];                             /* diagnostic builds only: fine-grained stamps (K3_FINE) */
     double prof[16];                              /* diagnostic builds only (-DSRBM_PROFILE): cycles per IPM phase */
     double dbg[4 * 64];

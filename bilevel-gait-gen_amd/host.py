@@ -353,13 +353,6 @@ class BatchMPC:
         self._chk(self.L.srbm_get_solve_flags(self.h, _i(f)))
         return f
 
-    def set_kernel_set(self, which):
-        """0: one instance per CU (512 threads, M in LDS); 1: two instances per CU (256 threads, M in L2) -- the default follows the batch size"""
-        self._chk(self.L.srbm_set_kernel_set(self.h, int(which)))
-
-    def kernel_set(self):
-        return int(self.L.srbm_get_kernel_set(self.h))
-
     def solver_step_rule(self):
         a = C.c_double(0); b = C.c_double(0)
         self._chk(self.L.srbm_get_solver_step_rule(self.h, C.byref(a), C.byref(b)))

@@ -88,14 +88,6 @@ int srbm_get_solver_step_rule(const srbm_batch* h, double* tol_step, double* sta
 /* flags[batch] of the LAST solve: bit 0 = ended through the step rule (duals not at the gap tolerance), bit 1 = began with a lower-start attempt,
  * bit 2 = that attempt was repeated from the standard starting point */
 int srbm_get_solve_flags(srbm_batch* h, int* flags);
-/* The library carries the kernels of the RTI path twice (same sources): set 0, one instance per CU (512 threads, the normal matrix of the solve in
- * LDS) and set 1, two instances per CU (256 threads, <= 80 KB of LDS, the normal matrix in L2).  Every batch is created on set 0;
- * srbm_set_kernel_set chooses (-1 where set 1 does not exist: the LARGE build, horizons whose working set exceeds half a CU).  Set 1 was the
- * faster one for batches beyond the CU count until round 4 (two instances filling each other's latency gaps: Config D -17 % in round 3); with
- * the round-4 kernels two standard rounds beat one co-resident round (Config D 7.02 vs 7.42 ms per step).  Same algorithm, same data; the results of
- * the two sets agree to rounding (reductions over 4 instead of 8 waves), not bit for bit. */
-int srbm_set_kernel_set(srbm_batch* h, int which);
-int srbm_get_kernel_set(const srbm_batch* h);
 
 /* MPC::CreateInitialRun (mpc/mpc.cpp:78-90): 10 solves at t = 0.   state[batch][13], ee[batch][4][3] */
 int srbm_create_initial_run(srbm_batch* h, const double* state, const double* ee_start_locations);

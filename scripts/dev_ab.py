@@ -19,7 +19,6 @@ if len(sys.argv) > 1 and sys.argv[1] == '--child':
     g = host.BatchMPC(cfg, B); g.set_state_trajectory_warm_start(states)
     if 'AB_TOL' in os.environ: g.set_solver_tolerances(float(os.environ['AB_TOL']), float(os.environ['AB_TOL']), 1e-10, 200)
     if 'AB_STEP' in os.environ: g.set_solver_step_rule(float(os.environ['AB_STEP']), float(os.environ.get('AB_MU', 0)))
-    if 'AB_SET' in os.environ: g.set_kernel_set(int(os.environ['AB_SET']))       # 0: one workgroup per CU, 1: the co-resident set
     for _ in range(10): g.create_initial_run(states, ees)
     g.rti_advance(0, 5); g.synchronize()
     if os.environ.get('AB_WINDOWS'):      # five 20-step launches timed one by one (the bench's timed regions)

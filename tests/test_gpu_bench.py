@@ -61,15 +61,13 @@ def run_bench(*args):
 
 def test_config_d_full_per_gpu_share_through_the_bench():
     """BASELINE config 4's per-GPU share AT FULL SIZE -- 512 instances, N = 50, push distribution -- through bench.py --workload D as a child
-    process (the protocol whose numbers DESIGN.md quotes): every timed solve accounted for through the sticky accumulators, no error bit, the
-    batch on the standard kernel set (two rounds of 256 workgroups: faster than one co-resident round since round 4), and the only solves that do not end Solved belong to the pushed instances whose QPs the ORACLE's solver
+    process (the protocol whose numbers DESIGN.md quotes): every timed solve accounted for through the sticky accumulators, no error bit, and the only solves that do not end Solved belong to the pushed instances whose QPs the ORACLE's solver
     finds primal infeasible as well (tests/test_gpu_parity.py::test_infeasible_qps_of_the_pushed_configuration_are_infeasible_for_the_oracle_too
     exports exactly those QPs and solves them with the restatement)."""
     d = run_bench('--workload', 'D', '--no-cpu-baseline', '--closed-loop-steps', '0')
     c = d['config']
     assert c['batch_per_gpu'] == 512 and c['num_nodes'] == 50 and c['records_gathered'] == 512
     assert c['timed_solves'] == 512 * d['steps'] * d['repeats'] and c['err_bits_all_timed_steps'] == 0 and c['max_iter_in_timed_solves'] == 0
-    assert c['kernel_set'] == 0
     assert set(c['instances_with_a_solve_not_solved_rank0']) <= {150, 441}, c['instances_with_a_solve_not_solved_rank0']
     assert c['not_solved_in_timed_solves'] <= 2 * d['steps'] * d['repeats']
     assert d['value'] > 4e4, d['value']
