@@ -6,13 +6,22 @@ apps/a1_configuration.yaml values, synthetic initial states (seeds 20240112+b, n
 Protocol: 10 cold-start solves per instance (MPC::CreateInitialRun, untimed set-up), W warm-up RTI steps, then the timed
 region: K RTI steps with t_i = i*dt and state := node 1 of the previous trajectory (test/gait_opt_playground.cpp:113-126),
 device-resident (inputs are in HBM when the region starts), closed by the all-gather of the result records.  The region is
-repeated `--repeats` times back to back (the protocol simply continues) and the MEDIAN region is reported, so that a
-20-step and a 100-step run agree (the first region after start-up runs at ramping clocks).  One "step" = one RTI iteration
-of every instance of the batch (shift -> assemble -> condense -> QP solve -> line search -> trajectory update).
+repeated `--repeats` times back to back (the protocol simply continues): with the defaults that is BASELINE.md section 3.3's
+protocol, 10 cold starts then 100 CONSECUTIVE timed steps (5 regions of 20), and `value` = instances x (steps x repeats) /
+SUM of the regions -- the transient after the cold start included (the median region and the settled rate stand beside it,
+named as such).  One "step" = one RTI iteration of every instance of the batch (shift -> assemble -> condense -> QP solve ->
+line search -> trajectory update).
+
+Solver mode of the headline (`--mode`, default `lower_start`): EVERY solve ends by the reference's termination test (Clarabel's
+gap 1e-15 / feasibility 1e-10, clarabel_interface.cpp:165-175); in the K-step launches a solve is first attempted from the
+linearisation point (srbm_set_solver_step_rule(0, 0.1)) and repeated from Clarabel's starting point when that fails.
+`reference_criterion` (library default (0, 0): Clarabel's start for every solve) and `step_rule_mode` (tol_step 1e-5: a LOOSER
+termination than the reference's, reported as a named secondary object, never as `value`) are the same protocol on fresh batches.
 
 Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); instances are sharded over ranks (weak scaling: 256
 per GPU) with no data-path collective; one all-gather of the per-instance result records (primal, dual, contact times)
-closes every timed region.  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment spawns the N ranks
+closes every timed region -- by default through the C-ABI (srbm_allgather_results: in-place ncclAllGather on the batch's stream,
+communicator from srbm_rccl_comm_init_rank; `--collective torch` uses torch.distributed's all_gather_into_tensor instead).  `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment spawns the N ranks
 itself (fresh child processes, the parent never touches a GPU); under torchrun the ranks are already there.  Rank 0 prints
 ONE JSON line.  `--dry-run` walks the same launcher / sharding / gather path on CPU (gloo) without any HIP call.
 """
@@ -29,22 +38,16 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from srbm_loader import workloads                      # (numpy only: the launcher parent never imports torch or touches a GPU)
+from srbm_loader.workloads import shard_range, config_b_instance, config_c_instance, config_d_instance
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (public spec; the CDNA guide lists no fp64 row)
 MFMA_FLOP = 2048.0           # one v_mfma_f64_16x16x4_f64: 16 x 16 x 4 multiply-adds
 BATCH_PER_GPU = 256
-PROFILE_ROUND = 'r04'
+PROFILE_ROUND = 'r05'
 
 
 # ---------- helpers shared with the CPU (gloo) tests of the sharding logic ----------
-def shard_range(total, rank, world):
-    """contiguous block [lo, hi) of `total` instances owned by `rank`"""
-    per = total // world
-    rem = total % world
-    lo = rank * per + min(rank, rem)
-    return lo, lo + per + (1 if rank < rem else 0)
-
-
 def gather_records(rec, world):
     """all-gather of fixed-size per-instance result records (rows) over the ranks"""
     import torch
@@ -65,50 +68,6 @@ def max_over_ranks(value):
     t = torch.tensor([value], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
-
-
-def config_b_instance(cfg, b):
-    """instance b of Config B: perturbed initial state + foot positions"""
-    rng = np.random.Generator(np.random.MT19937(20240112 + b))
-    u = lambda lo, hi: lo + (hi - lo) * rng.random()
-    m = cfg['mass']
-    p = np.array([u(-0.02, 0.02), u(-0.02, 0.02), 0.30 + u(-0.01, 0.01)])
-    v = np.array([u(-0.5, 0.5), u(-0.5, 0.5), u(-0.1, 0.1)])
-    rpy = np.array([u(-0.05, 0.05), u(-0.05, 0.05), u(-0.05, 0.05)])
-    L = np.array([u(-0.1, 0.1), u(-0.1, 0.1), u(-0.1, 0.1)])
-    th = np.linalg.norm(rpy)
-    quat = np.concatenate([np.sin(th / 2) / th * rpy, [np.cos(th / 2)]])
-    state = np.concatenate([p, m * v, quat, L])
-    hips = np.array([[0.2055, 0.147], [0.2055, -0.147], [-0.1555, 0.147], [-0.1555, -0.147]])
-    ee = np.zeros((4, 3))
-    for e in range(4):
-        ee[e, 0] = p[0] + hips[e, 0] + u(-0.02, 0.02)
-        ee[e, 1] = p[1] + hips[e, 1] + u(-0.02, 0.02)
-    return state, ee
-
-
-def config_c_instance(cfg, b):
-    """instance b of Config C: Config B's perturbations around the srb_init of apps/a1_gait_opt_config.yaml
-    (height 0.34); the target of that file is x_des = y_des = 1"""
-    state, ee = config_b_instance(cfg, b)
-    state[2] += cfg['srb_init'][2] - 0.30
-    return state, ee
-
-
-def config_d_instance(cfg, b):
-    """instance b of Config D: apps/a1_config_distr_rejection.yaml values (N=50, dt=0.02); the file's
-    single push becomes a distribution -- lin-mom xy ~ N(0, 2.5^2) truncated at 3 sigma, yaw ang-mom ~ N(0, 0.2^2), seed 777 + b"""
-    rng = np.random.Generator(np.random.MT19937(777 + b))
-    def tnorm(sig):
-        while True:
-            v = rng.normal(0.0, sig)
-            if abs(v) <= 3 * sig:
-                return v
-    state = np.array(cfg['srb_init'], float)
-    state[3] += tnorm(2.5); state[4] += tnorm(2.5)
-    state[12] += rng.normal(0.0, 0.2)
-    ee = np.array([[0.2, 0.2, 0], [0.2, -0.2, 0], [-0.2, 0.2, 0], [-0.2, -0.2, 0]], float)      # test/simulation_mpc.cpp:104-108
-    return state, ee
 
 
 # ---------- CPU baseline: the oracle's C++ driver, built and run on THIS box ----------
@@ -248,7 +207,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps run back to back; the median is reported')
+    ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps run back to back: value = instances x steps x repeats / their SUM')
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='instances per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', choices=['B', 'D', 'E'], default='B',
@@ -263,8 +222,13 @@ def main():
     ap.add_argument('--steady-from', type=int, default=125,
                     help='first RTI step of the extra `steady_state` regions (the protocol of the headline continued on the same batch past the '
                          'transient that follows the cold start; 0 = skip).  The headline `value` is not affected')
-    ap.add_argument('--no-reference-criterion', action='store_true', help='skip the second run of the Config-B protocol at the reference\'s gap criterion')
-    ap.add_argument('--reference-criterion-only', action='store_true', help='the headline itself at the reference\'s criterion (no step rule, no lower start)')
+    ap.add_argument('--mode', choices=['lower_start', 'reference', 'step_rule'], default='lower_start',
+                    help='solver mode of the headline: lower_start (default) = every solve ends by the reference\'s gap criterion, attempted first from the '
+                         'linearisation point (0, 0.1); reference = the library default (0, 0); step_rule = tol_step 1e-5 + lower start (looser termination)')
+    ap.add_argument('--no-reference-criterion', '--no-other-modes', dest='no_other_modes', action='store_true',
+                    help='skip the runs of the Config-B protocol in the two other solver modes')
+    ap.add_argument('--collective', choices=['cabi', 'torch'], default='cabi',
+                    help='all-gather of the result records: cabi (default) = srbm_allgather_results (RCCL through the C-ABI), torch = torch.distributed')
     ap.add_argument('--extra-workloads', type=int, default=1, help='1 (default): short Config D and Config E runs quoted as config_d / config_e objects (workload B only)')
     ap.add_argument('--n1-baseline', type=float, default=float(os.environ.get('SRBM_BENCH_N1_BASELINE', '0') or 0),
                     help='it/s of the 1-GPU run of the same command: the line then carries weak_scaling_efficiency = value / (n_gpus * this)')
@@ -331,6 +295,42 @@ def main():
             os.environ['MASTER_PORT'] = str(free_port())      # (one-rank rehearsal: no peer needs to know it)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
+    # The all-gather that closes a timed region.  Default: through the C-ABI -- the library packs this rank's records into their slot of the
+    # gathered array and runs one in-place ncclAllGather on the batch's stream (include/srbm_rti.h: srbm_allgather_results); the communicator is
+    # made by the library's helpers, its unique id travels over the process group that is there for the barriers.  A batch that cannot make one
+    # says so on stderr and the run continues on torch.distributed's collective, named in the JSON line.
+    coll = {'kind': 'none (one rank, no process group)' if not DIST else args.collective, 'comm': None, 'note': None}
+
+    def make_comm(m):
+        """ONE ncclComm_t per rank for all batches of the run (a communicator belongs to the device, not to a batch; created outside every timed
+        region through the first batch that gathers)"""
+        idb = [m.rccl_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(idb, src=0)
+        return m.rccl_comm_init_rank(world, rank, idb[0])
+
+    def gather_dev(m, rec_all, rec_mine):
+        """all ranks' records into rec_all [world * batch][ld] (returns it); rec_mine: this rank's slot (a view) for the torch path"""
+        if not DIST:
+            m.pack_results_dev(rec_all.data_ptr(), rec_all.shape[1])
+            m.synchronize()
+            return rec_all
+        if coll['kind'] == 'cabi':
+            if coll['comm'] is None:
+                try:
+                    coll['comm'] = make_comm(m)
+                except Exception as e:          # loud, and recorded in the line: never a silent switch
+                    sys.stderr.write('bench.py: C-ABI RCCL communicator failed (%s); continuing on torch.distributed all_gather\n' % e)
+                    coll['kind'] = 'torch'; coll['note'] = 'srbm_rccl_comm_init_rank failed: %s' % e
+            if coll['kind'] == 'cabi':
+                m.allgather_results(coll['comm'], rec_all.data_ptr())
+                m.synchronize()
+                return rec_all
+        m.pack_results_dev(rec_mine.data_ptr(), rec_mine.shape[1])
+        m.synchronize()
+        dist.all_gather_into_tensor(rec_all, rec_mine)
+        return rec_all
+
     def solved_quality(acc):
         """[error bits, solves, not solved, max-iter] of ALL timed solves (sticky accumulators), reduced over the ranks"""
         q = np.array([float(np.bitwise_or.reduce(acc[:, 0])), float(acc[:, 1].sum()), float(acc[:, 2].sum()), float(acc[:, 3].sum())])
@@ -342,28 +342,34 @@ def main():
             q = np.array([float(np.bitwise_or.reduce(allq[:, 0].astype(np.int64))), allq[:, 1].sum(), allq[:, 2].sum(), allq[:, 3].sum()])
         return q
 
-    def run_protocol(cfg_w, make_inst, per_gpu, large, fast, warmup, steps, repeats):
+    def set_mode(m, mode):
+        if mode == 'lower_start':
+            m.enable_lower_start()                            # srbm_set_solver_step_rule(0, 0.1): reference's termination test, lower starting point
+        elif mode == 'step_rule':
+            m.enable_fast_termination()                       # srbm_set_solver_step_rule(1e-5, 0.1)
+        else:
+            m.set_solver_step_rule(0.0, 0.0)                  # the library default = the reference's solver settings
+
+    def run_protocol(cfg_w, make_inst, per_gpu, large, mode, warmup, steps, repeats):
         """The timed protocol on this rank's shard of `per_gpu * world` instances: 10 cold-start solves (untimed), `warmup` RTI steps, then `repeats`
         regions of `steps` device-resident RTI steps, each closed by packing the result records and the all-gather over the ranks; barrier +
-        synchronize on both sides of every region, max over ranks.  fast: srbm_set_solver_step_rule(SRBM_FAST_TOL_STEP, SRBM_FAST_START_MU);
-        otherwise the library default = the reference's gap criterion."""
+        synchronize on both sides of every region, max over ranks.  mode: lower_start | reference | step_rule (set_mode)."""
         lo_, hi_ = shard_range(per_gpu * world, rank, world)
         st_, ee_ = zip(*[make_inst(cfg_w, b) for b in range(lo_, hi_)])
         st_, ee_ = np.array(st_), np.array(ee_).reshape(hi_ - lo_, 12)
         m = host.BatchMPC(cfg_w, hi_ - lo_, device=local_rank, large=large)
         m.set_state_trajectory_warm_start(st_)
         m.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)     # ClarabelInterface's settings (clarabel_interface.cpp:165-175)
-        if fast == 'low':
-            m.enable_lower_start()                            # reference's termination criterion, lower starting point (srbm_set_solver_step_rule(0, 0.1))
-        elif fast:
-            m.enable_fast_termination()
+        set_mode(m, mode)
         m.create_initial_run(st_, ee_)                        # 10 cold-start solves (set-up, untimed)
         m.rti_advance(0, warmup)
         m.synchronize()
         ld = m.result_record_doubles()                        # status..., primal, dual, contact times (SURVEY.md 8e record)
-        rec = torch.zeros((hi_ - lo_, ld), dtype=torch.float64, device='cuda')
+        nb_ = hi_ - lo_
+        rec_all = torch.zeros((world * nb_, ld), dtype=torch.float64, device='cuda')
+        rec_mine = rec_all[rank * nb_:(rank + 1) * nb_]
         if DIST:                                              # first collective outside the timed region (communicator set-up)
-            gather_records(rec, world)
+            gather_dev(m, rec_all, rec_mine)
             torch.cuda.synchronize()
         m.clear_status_accumulators()
         prev = m.work_counters() + (m.executed_mfma(),)
@@ -371,16 +377,13 @@ def main():
         m.enable_kernel_timing(repeats + 2)                   # every timed region is ONE launch of the fused RTI kernel
         reg_s, reg_local, reg_work = [], [], []               # max over ranks; this rank's own; (IPM iterations, algorithmic flops, executed MFMA) per region
         first = warmup
-        allrec_ = None
         for rep in range(repeats):
             if DIST:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             m.rti_advance(first, steps)                       # K device-resident RTI steps
-            m.pack_results_dev(rec.data_ptr(), ld)
-            m.synchronize()
-            allrec_ = gather_records(rec, world)              # RCCL all-gather of the solved trajectories (primal + dual + schedule)
+            gather_dev(m, rec_all, rec_mine)                  # RCCL all-gather of the solved trajectories (primal + dual + schedule)
             torch.cuda.synchronize()
             if DIST:
                 dist.barrier()
@@ -391,20 +394,22 @@ def main():
             reg_work.append(tuple(x - y for x, y in zip(ctr, prev)))
             prev = ctr
             first += steps
-        med_ = int(np.argsort(reg_s)[len(reg_s) // 2])        # the region `value` is computed from
+        med_ = int(np.argsort(reg_s)[len(reg_s) // 2])
         acc = m.status_accumulated()
         return dict(mpc=m, lo=lo_, hi=hi_, n_inst=per_gpu * world, region_s=reg_s, region_local_s=reg_local, region_work=reg_work, med=med_,
-                    elapsed=float(np.median(reg_s)), launch_ms=m.kernel_timings(repeats + 2), acc=acc, q=solved_quality(acc),
-                    counters=m.solver_counters(), allrec=allrec_, ld=ld, states=st_, ees=ee_,
+                    elapsed=float(np.sum(reg_s)), median_region=float(np.median(reg_s)), launch_ms=m.kernel_timings(repeats + 2), acc=acc, q=solved_quality(acc),
+                    counters=m.solver_counters(), allrec=rec_all, ld=ld, states=st_, ees=ee_, mode=mode,
                     mean_iters=(prev[0] - it_first) / max(1, (hi_ - lo_) * steps * repeats))
 
     def summary(r, steps, label):
         """short object for the extra workloads / criteria quoted beside the headline"""
         q_ = r['q']
-        el = r['elapsed']
+        el, nrep = r['elapsed'], len(r['region_s'])
         m = r['mpc']
         ts, mu = m.solver_step_rule()
-        return {'workload': label, 'value': r['n_inst'] * steps / el, 'unit': 'it/s', 'ms_per_step': 1e3 * el / steps, 'steps': steps, 'repeats': len(r['region_s']),
+        return {'workload': label, 'mode': r['mode'], 'value': r['n_inst'] * steps * nrep / el, 'unit': 'it/s', 'ms_per_step': 1e3 * el / (steps * nrep), 'steps': steps, 'repeats': nrep,
+                'statistic': 'instances x steps x repeats / SUM of the regions (consecutive steps after the cold start)',
+                'value_from_median_region': r['n_inst'] * steps / r['median_region'],
                 'region_ms': [1e3 * v for v in r['region_s']], 'batch_per_gpu': r['hi'] - r['lo'], 'global_batch': r['n_inst'], 'num_nodes': m.N,
                 'large_build': bool(m.large), 'records_gathered': int(r['allrec'].shape[0]),
                 'mean_ipm_iterations': r['mean_iters'], 'timed_solves': int(q_[1]), 'not_solved_in_timed_solves': int(q_[2]),
@@ -413,40 +418,52 @@ def main():
                 'solver': {'tol_gap': 1e-15, 'tol_feas': 1e-10, 'tol_step': ts, 'start_mu': mu, 'solves_ended_by_step_rule': r['counters']['step_rule'],
                            'lower_start_attempts': r['counters']['low_tried'], 'attempts_repeated_from_standard_start': r['counters']['low_failed']}}
 
-    FAST = not args.reference_criterion_only
-    main = run_protocol(cfg, make_instance, B, args.workload == 'E', FAST, args.warmup, args.steps, args.repeats)
+    MODE = args.mode
+    MODE_TEXT = {'lower_start': 'every solve ENDS by the reference criterion (gap 1e-15, feasibility 1e-10) and is first attempted from the linearisation point with '
+                                'centred multipliers (srbm_set_solver_step_rule(0, 0.1)): same termination test as the reference, other starting point',
+                 'reference': 'every solve to the reference criterion from Clarabel\'s starting point (srbm_set_solver_step_rule(0, 0): the library default, what a '
+                              'caller of the mpc:: facade gets)',
+                 'step_rule': 'solves end by the STEP RULE (tol_step 1e-5: the affine Newton step bounds the distance to the minimiser) -- a looser termination '
+                              'than the reference\'s gap 1e-15 -- with the lower starting point (srbm_set_solver_step_rule(1e-5, 0.1))'}
+    main = run_protocol(cfg, make_instance, B, args.workload == 'E', MODE, args.warmup, args.steps, args.repeats)
     mpc, states, ees = main['mpc'], main['states'], main['ees']
     region_s, region_work, med, elapsed = main['region_s'], main['region_work'], main['med'], main['elapsed']
     k3_each = main['launch_ms']; k3_launches = len(k3_each)
     acc_main, ctrs, allrec, LD, q = main['acc'], main['counters'], main['allrec'], main['ld'], main['q']
 
-    # ---- the same protocol at the REFERENCE'S termination criterion (gap 1e-15, no step rule, no lower start: clarabel_interface.cpp:165-175),
-    # i.e. what a caller of the mpc:: facade gets; the like-for-like number beside the CPU baseline, which iterates to that criterion too ----
-    ref_stats = ref_low_stats = None
-    if FAST and args.workload == 'B' and not args.no_reference_criterion:
-        rr = run_protocol(cfg, make_instance, B, False, False, args.warmup, args.steps, max(3, min(args.repeats, 5)))
-        ref_stats = summary(rr, args.steps, 'Config B, same protocol, every solve to the reference criterion (srbm_set_solver_step_rule(0, 0): the library default)')
-        del rr
-        rl = run_protocol(cfg, make_instance, B, False, 'low', args.warmup, args.steps, max(3, min(args.repeats, 5)))
-        ref_low_stats = summary(rl, args.steps, 'Config B, same protocol, every solve ENDS by the reference criterion (gap 1e-15) but is first attempted from the '
-                                                'linearisation point with centred multipliers (srbm_set_solver_step_rule(0, 0.1)): same termination test, other starting point')
-        del rl
-    # ---- BASELINE configs 4 and 5 at their per-GPU sizes, the same protocol with the same --steps / --warmup / --repeats (driver-visible numbers: VERDICT r3 item 4) ----
+    # ---- the same protocol in the two OTHER solver modes, on fresh batches: `reference_criterion` = the library default (0, 0), the like-for-like
+    # number beside the CPU baseline, which runs Clarabel's start to Clarabel's criterion too; `step_rule_mode` = the looser termination ----
+    other = {}
+    if args.workload == 'B' and not args.no_other_modes:
+        for mo in ('reference', 'lower_start', 'step_rule'):
+            if mo != MODE:
+                rr = run_protocol(cfg, make_instance, B, False, mo, args.warmup, args.steps, args.repeats)
+                other[mo] = summary(rr, args.steps, 'Config B, same protocol: ' + MODE_TEXT[mo])
+                del rr
+    # ---- BASELINE configs 4 and 5 at their per-GPU sizes, the same protocol with the same --steps / --warmup / --repeats, in the headline's mode
+    # (Config D also in the step-rule mode: the number rounds 3-4 tracked) ----
     d_stats = e_stats = None
     if args.workload == 'B' and args.extra_workloads:
         cfg_d = host.load_config('a1_config_distr_rejection')
-        rd = run_protocol(cfg_d, config_d_instance, 512, False, FAST, args.warmup, args.steps, args.repeats)
-        d_stats = summary(rd, args.steps, 'Config D: 512 A1 SRBM MPC instances per GPU, N=50, dt=0.02, a1_config_distr_rejection.yaml values, push distribution on the '
-                                  'initial momentum; not-solved solves belong to instances whose QPs the oracle finds infeasible too')
+        d_label = ('Config D: 512 A1 SRBM MPC instances per GPU, N=50, dt=0.02, a1_config_distr_rejection.yaml values, push distribution on the '
+                   'initial momentum; not-solved solves belong to instances whose QPs the oracle finds infeasible too')
+        rd = run_protocol(cfg_d, config_d_instance, 512, False, MODE, args.warmup, args.steps, args.repeats)
+        d_stats = summary(rd, args.steps, d_label)
         del rd
+        if MODE != 'step_rule':
+            rd = run_protocol(cfg_d, config_d_instance, 512, False, 'step_rule', args.warmup, args.steps, args.repeats)
+            d_stats['step_rule_mode'] = summary(rd, args.steps, d_label)
+            del rd
         cfg_e = host.load_config('a1_configuration', num_nodes=40)
-        re_ = run_protocol(cfg_e, config_b_instance, 128, True, FAST, args.warmup, args.steps, args.repeats)
+        re_ = run_protocol(cfg_e, config_b_instance, 128, True, MODE, args.warmup, args.steps, args.repeats)
         e_stats = summary(re_, args.steps, 'Config E (SRBM stand-in for the dead centroidal MPC): 128 instances per GPU, N=40, dt=0.05, LARGE-capacity build')
         del re_
 
-    # ---- second segment (Config C): N=20 / dt=0.05 with the values of apps/a1_gait_opt_config.yaml, gait step every 5th iteration ----
-    gait_stats = None
-    if args.gait_steps > 0 and args.workload == 'B':
+    # ---- second segment (Config C): N=20 / dt=0.05 with the values of apps/a1_gait_opt_config.yaml, gait step every 5th iteration.
+    # No lower-start attempts in this protocol (one-step launches).  In the headline's default mode every solve of the segment runs to the gap
+    # criterion; `step_rule_mode` beside it = plain steps and line-search candidates end by the step rule (the differentiated solve always runs to the
+    # gap criterion: srbm_gait_rti_advance does that by itself) ----
+    def gait_segment(step_rule):
         FREQ = 5
         cfg_c = host.load_config('a1_gait_opt_config', num_nodes=20, integrator_dt=0.05)
         sc, ec = zip(*[config_c_instance(cfg_c, b) for b in range(lo, hi)])
@@ -454,9 +471,8 @@ def main():
         gm = host.BatchMPC(cfg_c, hi - lo, device=local_rank)
         gm.set_state_trajectory_warm_start(sc)
         gm.set_solver_tolerances(1e-15, 1e-15, 1e-10, 200)
-        if FAST:
-            gm.enable_fast_termination()     # plain steps and line-search candidates end by the step rule; the solve whose KKT system is differentiated
-                                             # runs to the gap criterion (srbm_gait_rti_advance does that by itself); no lower-start attempts in this protocol
+        if step_rule:
+            gm.enable_fast_termination()
         gm.create_initial_run(sc, ec)
         gait = host.BatchGaitOptimizer(gm)
         gait.rti_advance(0, 6, FREQ)                 # run_num 0..5: includes one gradient + LP (run 4) and one line search (run 5)
@@ -479,23 +495,30 @@ def main():
         accg = gm.status_accumulated()
         lp_st, _ = gait.lp_result()
         solves = n_inst * ((args.gait_steps - n_ls) + 10 * n_ls)      # a line search is 10 RTI solves per instance
-        gait_stats = {'workload': 'Config C: %d instances per GPU, N=20, dt=0.05, a1_gait_opt_config.yaml values (mu 0.6, force bound 200, target x=y=1); '
-                                  'controller protocol with the gait step every 5th iteration (gradient + LP, then 10-candidate line search)' % B,
-                      'solver_tol_step': gm.solver_step_rule()[0],
-                      'steps': args.gait_steps, 'gait_opt_steps': n_go, 'line_search_steps': n_ls,
-                      'rti_solves_per_s_incl_line_search': solves / el_g, 'gait_steps_per_s': n_inst * n_ls / el_g,
-                      'ms_per_step': 1e3 * el_g / args.gait_steps,
-                      'statuses_after': {int(k): int(v) for k, v in zip(*np.unique(stg, return_counts=True))},
-                      'err_bits_all_steps': int(np.bitwise_or.reduce(accg[:, 0])), 'not_solved_all_steps': int(accg[:, 2].sum()),
-                      'lp_status_last': {int(k): int(v) for k, v in zip(*np.unique(lp_st, return_counts=True))}}
+        out_g = {'workload': 'Config C: %d instances per GPU, N=20, dt=0.05, a1_gait_opt_config.yaml values (mu 0.6, force bound 200, target x=y=1); '
+                             'controller protocol with the gait step every 5th iteration (gradient + LP, then 10-candidate line search)' % B,
+                 'solver_tol_step': gm.solver_step_rule()[0],
+                 'steps': args.gait_steps, 'gait_opt_steps': n_go, 'line_search_steps': n_ls,
+                 'rti_solves_per_s_incl_line_search': solves / el_g, 'gait_steps_per_s': n_inst * n_ls / el_g,
+                 'ms_per_step': 1e3 * el_g / args.gait_steps,
+                 'statuses_after': {int(k): int(v) for k, v in zip(*np.unique(stg, return_counts=True))},
+                 'err_bits_all_steps': int(np.bitwise_or.reduce(accg[:, 0])), 'not_solved_all_steps': int(accg[:, 2].sum()),
+                 'lp_status_last': {int(k): int(v) for k, v in zip(*np.unique(lp_st, return_counts=True))}}
         del gait, gm
+        return out_g
+
+    gait_stats = None
+    if args.gait_steps > 0 and args.workload == 'B':
+        gait_stats = gait_segment(MODE == 'step_rule')
+        if MODE != 'step_rule':
+            gait_stats['step_rule_mode'] = gait_segment(True)
     # ---- third segment: closed-loop rollouts, plant = SRBM dynamics under the current trajectory + one push per instance ----
     cl_stats = None
     if args.closed_loop_steps > 0:
         SUB = 10
         cl = host.BatchMPC(cfg, hi - lo, device=local_rank, large=mpc.large)
         cl.set_state_trajectory_warm_start(states)
-        if FAST:
+        if MODE == 'step_rule':
             cl.enable_fast_termination()     # (step rule only: under a plant the library ignores start_mu)
         cl.create_initial_run(states, ees)
         cl.plant_set_state(states)
@@ -598,18 +621,19 @@ def main():
                                                  'srbm_qp_control_dev; contact forces stacked on the device): no copy, no synchronisation inside a tick',
                                          'ms_per_tick_of_the_batch': 1e3 * el_d / args.wbc_ticks, 'control_actions_per_s': n_inst * args.wbc_ticks / el_d,
                                          'targets_not_ok': int(bad_d[0]), 'qp_not_solved': int(bad_d[1])}}
-    value = n_inst * args.steps / elapsed
+    value = n_inst * args.steps * args.repeats / elapsed          # `elapsed` = SUM of the timed regions
 
     # ---- the headline's protocol CONTINUED on the same batch: `repeats` more regions of `steps` steps from step `--steady-from` on.  The five
     # regions of the headline cover the first ~100 steps after the cold start, where the lower-start attempts still fail more often and the
     # solves are longer; a controller that runs for seconds sees the rate below.  Reported beside `value`, never instead of it ----
     steady = None
-    if args.steady_from > 0 and args.workload == 'B' and not args.reference_criterion_only:
+    if args.steady_from > 0 and args.workload == 'B':
         first_s = args.warmup + args.steps * args.repeats
         if args.steady_from > first_s:
             mpc.rti_advance(first_s, args.steady_from - first_s)          # untimed
             first_s = args.steady_from
-        rec_s = torch.zeros((hi - lo, main['ld']), dtype=torch.float64, device='cuda')
+        rec_s = allrec
+        rec_s_mine = rec_s[rank * (hi - lo):(rank + 1) * (hi - lo)]
         mpc.synchronize()
         reg_steady = []
         for rep in range(args.repeats):
@@ -618,18 +642,16 @@ def main():
             torch.cuda.synchronize()
             t0s = time.perf_counter()
             mpc.rti_advance(first_s, args.steps)
-            mpc.pack_results_dev(rec_s.data_ptr(), main['ld'])
-            mpc.synchronize()
-            gather_records(rec_s, world)
+            gather_dev(mpc, rec_s, rec_s_mine)
             torch.cuda.synchronize()
             if DIST:
                 dist.barrier()
             reg_steady.append(max_over_ranks(time.perf_counter() - t0s))
             first_s += args.steps
-        el_s = float(np.median(reg_steady))
+        el_s = float(np.sum(reg_steady))
         st_s, err_s = mpc.status()
-        steady = {'value': n_inst * args.steps / el_s, 'unit': 'it/s', 'ms_per_step': 1e3 * el_s / args.steps, 'region_ms': [1e3 * v for v in reg_steady],
-                  'first_step': first_s - args.steps * args.repeats, 'statistic': 'median of %d regions of %d steps, same bracket as the headline' % (args.repeats, args.steps),
+        steady = {'value': n_inst * args.steps * args.repeats / el_s, 'unit': 'it/s', 'ms_per_step': 1e3 * el_s / (args.steps * args.repeats), 'region_ms': [1e3 * v for v in reg_steady],
+                  'first_step': first_s - args.steps * args.repeats, 'statistic': 'instances x steps x repeats / SUM of %d regions of %d steps, same bracket as the headline' % (args.repeats, args.steps),
                   'all_solved_after': bool(np.all(st_s <= 1) and np.all(err_s == 0)),
                   'note': 'the protocol of `value` continued on the same batch past the transient after the cold start (its regions are steps %d..%d); '
                           '`value` and `roofline` describe the regions of the headline only' % (args.warmup, args.warmup + args.steps * args.repeats)}
@@ -646,11 +668,12 @@ def main():
         err_all = allrec[:, 5].cpu().numpy().astype(np.int64)
         if allrec.shape[0] != n_inst:
             raise SystemExit('gathered %d records for %d instances' % (allrec.shape[0], n_inst))
-        # the roofline object describes the SAME region `value` does: the median one -- its own launch duration (HIP events on the launch
-        # stream), its own flop and MFMA counts
-        k3_avg_s = float(k3_each[med]) * 1e-3 if med < k3_launches else 0.0
-        flops_per_launch = region_work[med][1]
-        mfma_per_launch = region_work[med][2]
+        # the roofline object describes the SAME regions `value` does: all timed launches -- average launch duration (HIP events on the launch
+        # stream), average flop and MFMA counts per launch
+        n_l = min(k3_launches, len(region_work))
+        k3_avg_s = float(np.mean(k3_each[:n_l])) * 1e-3 if n_l else 0.0
+        flops_per_launch = float(np.mean([w_[1] for w_ in region_work[:n_l]])) if n_l else 0.0
+        mfma_per_launch = float(np.mean([w_[2] for w_ in region_work[:n_l]])) if n_l else 0.0
         achieved = flops_per_launch / k3_avg_s / 1e12 if k3_avg_s > 0 else 0.0
         exec_tflops = mfma_per_launch * MFMA_FLOP / k3_avg_s / 1e12 if k3_avg_s > 0 else 0.0
         traffic, pmc = pmc_traffic(args.steps) if args.workload == 'B' else (None, None)
@@ -659,12 +682,12 @@ def main():
         roof = {'bound': 'mfma', 'limiter': 'latency',
                 'limiter_detail': 'latency of dependent chains (1 workgroup of 8 waves per CU, no HBM or matrix-pipe saturation); frac is measured against '
                                   'the fp64 matrix roof, the nearest one',
-                'statistic': 'median region (index %d of %d): the launch `value` is computed from' % (med, len(region_s)),
+                'statistic': 'averages over the %d timed launches (one per region) that `value` is computed from' % n_l,
                 'launch_ms_all': [float(v) for v in k3_each],
                 'kernel': ('srbm_rti_fused' if cfg['num_nodes'] <= 22 else 'srbm_rti_fused_long') + (' (LARGE build)' if mpc.large else ''),
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / FP64_PEAK_TFLOPS,
                 'achieved_is': 'ALGORITHMIC flops (SURVEY.md 8d formula at the sizes and IPM iteration counts executed) / measured launch time',
-                'traffic': traffic, 'avg_launch_ms': k3_avg_s * 1e3, 'launches_timed': k3_launches, 'ipm_iterations_per_solve_in_this_launch': region_work[med][0] / max(1, (hi - lo) * args.steps),
+                'traffic': traffic, 'avg_launch_ms': k3_avg_s * 1e3, 'launches_timed': k3_launches, 'ipm_iterations_per_solve': float(np.mean([w_[0] for w_ in region_work[:n_l]])) / max(1, (hi - lo) * args.steps) if n_l else 0.0,
                 'algorithmic_flops_per_launch': flops_per_launch,
                 'executed_mfma_tflops': exec_tflops, 'executed_mfma_frac_of_peak': exec_tflops / FP64_PEAK_TFLOPS,
                 'executed_mfma_instructions_per_launch': mfma_per_launch}
@@ -676,10 +699,16 @@ def main():
         out = {
             'metric': 'MPC RTI iterations/sec (batched A1 SRBM, N=%d)' % cfg['num_nodes'],
             'value': value, 'unit': 'it/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': 1e3 * elapsed / (args.steps * args.repeats), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic', 'repeats': args.repeats, 'region_ms': [1e3 * v for v in region_s],
-            'region_mean_ms': 1e3 * float(np.mean(region_s)), 'value_from_mean_region': n_inst * args.steps / float(np.mean(region_s)),
-            'statistic': 'value = instances x steps / MEDIAN region (max over ranks); the first region follows the cold start',
+            'statistic': 'value = instances x (steps x repeats) / SUM of the timed regions (max over ranks each): %d CONSECUTIVE RTI steps after the 10 cold starts '
+                         'and the warm-up, the transient of the first region included (BASELINE.md section 3.3)' % (args.steps * args.repeats),
+            'solver_mode': MODE, 'solver_mode_is': MODE_TEXT[MODE],
+            'median_region': {'value': n_inst * args.steps / main['median_region'], 'ms_per_step': 1e3 * main['median_region'] / args.steps,
+                              'note': 'instances x steps / MEDIAN region: the settled rate of the same run (rounds 1-4 reported this as `value`)'},
+            'collective': {'path': ('C-ABI: srbm_allgather_results (in-place ncclAllGather on the batch stream, communicator from srbm_rccl_comm_init_rank)'
+                                    if coll['kind'] == 'cabi' else coll['kind'] if not DIST else 'torch.distributed all_gather_into_tensor (backend nccl = RCCL)'),
+                           'note': coll['note']},
             'rccl_world_size': dist.get_world_size() if DIST else 1, 'per_rank_region_ms': per_rank_ms,
             'weak_scaling_efficiency': (value / (world * args.n1_baseline)) if args.n1_baseline > 0 else None,
             'config': {'workload': ('Config B: %d A1 SRBM MPC instances per GPU, N=20, dt=0.05, a1_configuration.yaml values, '
@@ -701,10 +730,9 @@ def main():
                                   'note': 'rank 0, all solves since the accumulators were cleared (timed regions; include/srbm_rti.h srbm_set_solver_step_rule)'}},
             'roofline': roof,
         }
-        if ref_stats is not None:
-            out['reference_criterion'] = ref_stats
-        if ref_low_stats is not None:
-            out['reference_criterion_lower_start'] = ref_low_stats
+        for mo, key in (('reference', 'reference_criterion'), ('lower_start', 'reference_criterion_lower_start'), ('step_rule', 'step_rule_mode')):
+            if mo in other:
+                out[key] = other[mo]
         if d_stats is not None:
             out['config_d'] = d_stats
         if e_stats is not None:
@@ -722,16 +750,18 @@ def main():
                 out['cpu_baseline'] = cpu_baseline(cfg)
                 cb = out['cpu_baseline']
                 cb['criterion'] = "the reference's: Clarabel restatement to gap 1e-15 (clarabel_interface.cpp:165-175)"
-                like = ref_stats['value'] if ref_stats is not None else (value if not FAST else None)
-                cb['like_for_like'] = {'gpu_value_at_the_same_criterion': like,
+                like = other['reference']['value'] if 'reference' in other else (value if MODE == 'reference' else None)
+                cb['like_for_like'] = {'gpu_value_at_the_same_criterion_and_starting_point': like, 'gpu_value_headline_mode': value,
                                        'speedup_vs_one_thread': (like / cb['value']) if like and cb['value'] else None,
                                        'speedup_vs_all_cores': (like / cb['all_cores']['value']) if like and cb['all_cores']['value'] else None,
-                                       'note': 'the headline `value` ends its solves by the step rule (config.solver) -- compare THIS pair for a like-for-like ratio'}
+                                       'note': 'the CPU restatement runs Clarabel\'s starting point to Clarabel\'s criterion: the (0, 0) run is the like-for-like pair; the headline mode ends every solve by the same criterion from a lower starting point'}
             except Exception as e:            # the GPU line stands on its own
                 out['cpu_baseline'] = {'value': None, 'unit': 'it/s', 'cores': 0, 'kind': 'port', 'sample': 'failed: %s' % e}
         print(json.dumps(out))
     if DIST:
         dist.barrier()
+        if coll['comm'] is not None:
+            mpc.rccl_comm_destroy(coll['comm'])
         dist.destroy_process_group()
 
 

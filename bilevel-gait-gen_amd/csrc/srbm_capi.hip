@@ -1,9 +1,13 @@
 // Host side of the batched SRBM RTI path: the C-ABI of include/srbm_rti.h over the HIP kernels.
 // Mirrors the call sequence of mpc::MPC / mpc::MPCSingleRigidBody (reference file:line cited in the header).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>          // types and prototypes only: RCCL is bound at run time (srbm_allgather_results), the library does not link it
+#include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -14,8 +18,6 @@
 #include "srbm_ik.hiph"
 #include "srbm_wbc.hiph"
 #include "../../include/srbm_rti.h"
-#ifndef SRBM_LARGE
-#endif
 
 #ifdef SRBM_LARGE
 #define SRBM_DYN_LDS(T) sizeof(T)        /* LARGE build: the working sets of kernels 1, 2, 4 exceed 64 KB of static LDS */
@@ -1199,6 +1201,97 @@ int srbm_pack_results(srbm_batch* h, double* out, int ld) {
     if (srbm_pack_results_dev(h, static_cast<double*>(d), ld)) return -1;
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, d, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---------------- multi-GPU: RCCL all-gather of the result records (include/srbm_rti.h) ----------------
+// RCCL is bound at run time (types from its header, no link dependency): a process that has a copy loaded -- a C++ host linked against
+// librccl.so.1, a Python process whose torch brought its own librccl.so -- gets THAT copy, so that a ncclComm_t made on the caller's side and the
+// calls made here belong to the same library.
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+};
+static RcclApi* rccl_api_ptr() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* forced = std::getenv("SRBM_RCCL_LIB");
+        const char* names[] = {"librccl.so", "librccl.so.1"};
+        if (forced) api.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        for (int pass = 0; pass < 2 && !api.lib && !forced; pass++)                   // pass 0: a copy already in the process, pass 1: load one
+            for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+        if (!api.lib) { const char* e = dlerror(); api.err = std::string("RCCL not found (librccl.so / librccl.so.1; SRBM_RCCL_LIB overrides): ") + (e ? e : ""); return; }
+        auto sym = [&](const char* n) { void* p = dlsym(api.lib, n); if (!p && api.err.empty()) api.err = std::string("RCCL symbol missing: ") + n; return p; };
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(sym("ncclCommUserRank"));
+        api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    return &api;
+}
+#define rccl_api() (*rccl_api_ptr())
+static int rccl_fail(const char* what, ncclResult_t r) {
+    RcclApi& A = rccl_api();
+    return fail(std::string(what) + ": " + (A.GetErrorString ? A.GetErrorString(r) : "RCCL error"));
+}
+static_assert(sizeof(ncclUniqueId) == SRBM_RCCL_UNIQUE_ID_BYTES, "include/srbm_rti.h states the size of ncclUniqueId");
+
+int srbm_rccl_get_unique_id(void* id_bytes) {
+    if (!id_bytes) return fail("bad arguments");
+    RcclApi& A = rccl_api();
+    if (!A.err.empty()) return fail(A.err);
+    ncclUniqueId id;
+    const ncclResult_t r = A.GetUniqueId(&id);
+    if (r != ncclSuccess) return rccl_fail("ncclGetUniqueId", r);
+    std::memcpy(id_bytes, &id, sizeof(id));
+    return 0;
+}
+int srbm_rccl_comm_init_rank(srbm_batch* h, int world, int rank, const void* id_bytes, ncclComm_t* comm_out) {
+    if (!h || !id_bytes || !comm_out || world < 1 || rank < 0 || rank >= world) return fail("bad arguments");
+    RcclApi& A = rccl_api();
+    if (!A.err.empty()) return fail(A.err);
+    HIPCHK(hipSetDevice(h->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, sizeof(id));
+    const ncclResult_t r = A.CommInitRank(comm_out, world, id, rank);
+    if (r != ncclSuccess) return rccl_fail("ncclCommInitRank", r);
+    return 0;
+}
+int srbm_rccl_comm_destroy(ncclComm_t comm) {
+    if (!comm) return 0;
+    RcclApi& A = rccl_api();
+    if (!A.err.empty()) return fail(A.err);
+    const ncclResult_t r = A.CommDestroy(comm);
+    if (r != ncclSuccess) return rccl_fail("ncclCommDestroy", r);
+    return 0;
+}
+int srbm_allgather_results(srbm_batch* h, ncclComm_t comm, double* out_dev) {
+    if (!h || !comm || !out_dev) return fail("bad arguments");
+    RcclApi& A = rccl_api();
+    if (!A.err.empty()) return fail(A.err);
+    HIPCHK(hipSetDevice(h->device));
+    int rank = -1, world = 0;
+    ncclResult_t r = A.CommUserRank(comm, &rank);
+    if (r == ncclSuccess) r = A.CommCount(comm, &world);
+    if (r != ncclSuccess) return rccl_fail("ncclCommUserRank / ncclCommCount", r);
+    if (rank < 0 || rank >= world) return fail("srbm_allgather_results: communicator reports an invalid rank");
+    const int ld = srbm_result_record_doubles(h->hp.N);
+    const size_t count = (size_t)h->batch * ld;
+    double* mine = out_dev + (size_t)rank * count;                  // in place: this rank's records go straight to their slot of the gathered array
+    if (srbm_pack_results_dev(h, mine, ld)) return -1;
+    r = A.AllGather(mine, out_dev, count, ncclDouble, comm, h->stream);
+    if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
     return 0;
 }
 

@@ -95,7 +95,7 @@ def build(force=False):
         with open(os.path.join(HERE, 'csrc', '.build.lock'), 'w') as lk:
             fcntl.flock(lk, fcntl.LOCK_EX)
             try:
-                subprocess.check_call(['make', '-s', '-j3', '-C', os.path.join(HERE, 'csrc')])
+                subprocess.check_call(['make', '-s', '-j2', '-C', os.path.join(HERE, 'csrc')])
             finally:
                 fcntl.flock(lk, fcntl.LOCK_UN)
     return LIB_PATH
@@ -524,6 +524,29 @@ class BatchMPC:
 
     def pack_results_dev(self, ptr, ld):
         self._chk(self.L.srbm_pack_results_dev(self.h, C.c_void_p(ptr), int(ld)))
+
+    # ---- multi-GPU: RCCL all-gather of the result records through the C-ABI (include/srbm_rti.h: srbm_allgather_results) ----
+    def rccl_unique_id(self):
+        """ncclGetUniqueId (one rank calls it, the 128 bytes travel to the others by the host's own rendezvous)"""
+        buf = (C.c_ubyte * 128)()
+        self._chk(self.L.srbm_rccl_get_unique_id(buf))
+        return bytes(buf)
+
+    def rccl_comm_init_rank(self, world, rank, id_bytes):
+        """ncclCommInitRank on the batch's device; returns the ncclComm_t as an integer handle"""
+        assert len(id_bytes) == 128
+        comm = C.c_void_p(0)
+        buf = (C.c_ubyte * 128).from_buffer_copy(id_bytes)
+        self._chk(self.L.srbm_rccl_comm_init_rank(self.h, int(world), int(rank), buf, C.byref(comm)))
+        return comm.value
+
+    def rccl_comm_destroy(self, comm):
+        self._chk(self.L.srbm_rccl_comm_destroy(C.c_void_p(comm)))
+
+    def allgather_results(self, comm, out_ptr):
+        """this rank's result records packed into their slot of out[world * batch][record_doubles] (device pointer) and ONE in-place ncclAllGather
+        on the batch's stream; asynchronous (synchronize() before reading)"""
+        self._chk(self.L.srbm_allgather_results(self.h, C.c_void_p(comm), C.c_void_p(out_ptr)))
 
     def pack_results(self):
         """the result records of srbm_pack_results_dev in a host array [batch][srbm_result_record_doubles(N)]"""

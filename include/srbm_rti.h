@@ -325,6 +325,25 @@ int srbm_result_record_doubles(int num_nodes);
 int srbm_pack_results_dev(srbm_batch* h, double* out_dev, int ld);
 /* the same records into a HOST buffer out[batch][ld] (synchronous) */
 int srbm_pack_results(srbm_batch* h, double* out, int ld);
+
+/* ---- multi-GPU: collecting the solved trajectories of all shards (north_star: "partitioned across the 8 GPUs of one node with an RCCL all-gather
+ * over xGMI only to collect solved trajectories"; the reference's only batch is the 10-thread line search, mpc/gait_optimizer.cpp:688-721; the host
+ * that would call this is the MPC thread of controllers/mpc_controller.cpp:286-399, one per GPU) ----
+ * One process per GPU, each owning a batch of the SAME size (contiguous shards of the global batch).  srbm_allgather_results packs this rank's
+ * result records (srbm_pack_results_dev layout, ld = srbm_result_record_doubles(N)) straight into its slot of out_dev and runs ONE in-place
+ * ncclAllGather (RCCL) on the batch's stream: out_dev[world * batch][ld] on every rank, rank r's records at rows [r * batch, (r + 1) * batch).
+ * Asynchronous like every *_dev entry: srbm_synchronize (or work queued behind it on srbm_get_stream) before out_dev is read.
+ * `comm` is a plain ncclComm_t of <rccl/rccl.h> -- the caller's own (ncclCommInitRank on its side), or one made by the helpers below for hosts
+ * that do not link RCCL themselves (ctypes, bench.py).  The library does not link RCCL: it binds the copy already loaded in the process
+ * (librccl.so / librccl.so.1), else loads librccl.so.1, at the first of these calls; SRBM_RCCL_LIB overrides the name.  No RCCL, no call: they fail loudly. */
+struct ncclComm;
+typedef struct ncclComm* ncclComm_t;               /* identical to the typedef in <rccl/rccl.h> */
+#define SRBM_RCCL_UNIQUE_ID_BYTES 128              /* sizeof(ncclUniqueId) */
+int srbm_allgather_results(srbm_batch* h, ncclComm_t comm, double* out_dev);
+/* ncclGetUniqueId on one rank (bytes travel to the others by whatever the host uses for its rendezvous), ncclCommInitRank on the batch's device, ncclCommDestroy */
+int srbm_rccl_get_unique_id(void* id_bytes);
+int srbm_rccl_comm_init_rank(srbm_batch* h, int world, int rank, const void* id_bytes, ncclComm_t* comm_out);
+int srbm_rccl_comm_destroy(ncclComm_t comm);
 /* measurement aids: HIP-event timing of the dominant kernel (srbm_k3_ipm) on the launch stream, and running totals
  * of executed IPM iterations / algorithmic flops (SURVEY.md section 8d formula) summed over the batch */
 int srbm_enable_kernel_timing(srbm_batch* h, int max_launches);

@@ -7,7 +7,7 @@ if len(sys.argv) > 1 and sys.argv[1] == '--child':
     sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
     import numpy as np
     from srbm_loader import host
-    import bench
+    from srbm_loader import workloads as bench
     wl = os.environ.get('AB_WORKLOAD', 'B')
     cfg = host.load_config() if wl == 'B' else host.load_config('a1_config_distr_rejection')
     B = 256 if wl == 'B' else 512

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, ROOT)
 from srbm_loader import host
 host.LIB_PATH = os.path.join(ROOT, 'bilevel-gait-gen_amd', os.environ.get('SRBM_PROF_LIB', 'libsrbm_rti_prof.so'))
-import bench
+from srbm_loader import workloads as bench
 cfg = host.load_config()
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 11
 s0, ee = bench.config_b_instance(cfg, b)

@@ -93,6 +93,41 @@ def test_cpp_host_side_equals_ctypes_path(tmp_path):
     assert np.array_equal(np.array(vals['x']), x[0, :40])
 
 
+# ---------------- the collective on the C side of the boundary (include/srbm_rti.h: srbm_allgather_results) ----------------
+def build_allgather_program(tmpdir):
+    cfg = host.load_config('a1_configuration')
+    host.build()
+    write_cfg_inc(cfg, os.path.join(tmpdir, 'cfg.inc'))
+    exe = os.path.join(tmpdir, 'cabi_allgather_smoke')
+    libdir = os.path.dirname(host.LIB_PATH)
+    rocm = os.environ.get('ROCM_PATH', '/opt/rocm')
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-Wall', '-Werror', '-D__HIP_PLATFORM_AMD__', '-I', os.path.join(ROOT, 'include'), '-I', os.path.join(rocm, 'include'),
+                           '-I', tmpdir, os.path.join(CPP, 'cabi_allgather_smoke.cpp'), '-o', exe, '-L', libdir, '-lsrbm_rti', '-L', os.path.join(rocm, 'lib'), '-lrccl',
+                           '-lamdhip64', '-Wl,-rpath,' + libdir, '-Wl,-rpath,' + os.path.join(rocm, 'lib')])
+    return cfg, exe
+
+
+def test_cpp_allgather_host_compiles_and_links(tmp_path):
+    """a C++ host that links RCCL itself and passes its own ncclComm_t across the C-ABI; the library itself must NOT depend on
+    RCCL at link time (it binds the process's copy at run time)"""
+    cfg, exe = build_allgather_program(str(tmp_path))
+    assert os.path.exists(exe)
+    needed = subprocess.check_output(['readelf', '-d', host.LIB_PATH], text=True)
+    assert 'librccl' not in needed
+
+
+@pytest.mark.gpu
+def test_cpp_allgather_of_one_rank_equals_the_packed_records(tmp_path):
+    """world size 1 on the one-GPU box: srbm_allgather_results (in-place ncclAllGather on the batch's stream) with the HOST's communicator and with
+    one from srbm_rccl_comm_init_rank both reproduce srbm_pack_results bit for bit"""
+    cfg, exe = build_allgather_program(str(tmp_path))
+    vals = parse_dump(subprocess.check_output([exe], text=True, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))))
+    g = host.BatchMPC(cfg, 1)
+    assert vals['record_doubles'] == [float(g.result_record_doubles())]
+    assert vals['own_comm_equal'] == [1.0] and vals['helper_comm_equal'] == [1.0]
+    assert all(v <= 1.0 for v in vals['status']) and len(set(vals['x0'])) == 3
+
+
 # ---------------- include/mpc_facade/mpc.h: the reference's own class names and signatures ----------------
 def build_callsites(tmpdir):
     cfg = host.load_config('a1_configuration')

@@ -34,6 +34,13 @@ def test_bench_line_under_torchrun_with_the_collective_path():
     assert d['n_gpus'] == 1 and d['steps'] == 4 and d['warmup'] == 2 and d['higher_is_better'] is True and d['scaling'] == 'weak'
     assert d['unit'] == 'it/s' and d['dtype'] == 'f64' and d['data'] == 'synthetic' and d['vs_baseline'] is None
     assert d['value'] > 1e4 and abs(d['value'] - 256 * 4 / (d['ms_per_step'] * 4 * 1e-3)) < 1e-6 * d['value']
+    # the headline: every solve ends by the reference's criterion (lower starting point); the step-rule mode and the library default stand beside it
+    assert d['solver_mode'] == 'lower_start' and d['config']['solver']['tol_step'] == 0.0 and d['config']['solver']['start_mu'] > 0
+    assert d['config']['solver']['solves_ended_by_step_rule'] == 0
+    assert d['step_rule_mode']['solver']['tol_step'] > 0 and d['reference_criterion']['solver']['start_mu'] == 0.0
+    assert d['median_region']['value'] >= 0.99 * d['value']
+    # the all-gather went through the C-ABI (srbm_allgather_results) with a world of one rank
+    assert d['collective']['path'].startswith('C-ABI') and d['collective']['note'] is None and d['rccl_world_size'] == 1
     c = d['config']
     assert 'workload' in c and c['global_batch'] == 256 and c['records_gathered'] == 256 and 'model' not in c
     assert c['timed_solves'] == 256 * 4 * 2 and c['err_bits_all_timed_steps'] == 0

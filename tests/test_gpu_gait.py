@@ -316,7 +316,7 @@ def seeded_batch_of_32():
     """BASELINE config 3 as the bench runs it (a1_gait_opt_config values at N = 20, dt = 0.05): 32 DIFFERENT seeded instances, each re-synchronised to
     its own oracle before every RTI step, after four steps (all solves at the gap criterion: the default of a new batch)"""
     from concurrent.futures import ThreadPoolExecutor
-    from bench import config_c_instance
+    from srbm_loader.workloads import config_c_instance
     cfg = load_config('a1_gait_opt_config', num_nodes=20, integrator_dt=0.05)
     B, NSTEPS = 32, 4
     states, ees = zip(*[config_c_instance(cfg, b) for b in range(B)])

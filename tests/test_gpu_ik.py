@@ -9,7 +9,7 @@ import pytest
 
 from oracle_py import OracleMPC, load_config
 from srbm_loader import host
-from bench import config_b_instance
+from srbm_loader.workloads import config_b_instance
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))

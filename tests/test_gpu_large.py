@@ -8,7 +8,7 @@ import pytest
 
 from oracle_py import OracleMPC, load_config
 from srbm_loader import host
-from bench import config_b_instance
+from srbm_loader.workloads import config_b_instance
 
 pytestmark = pytest.mark.gpu
 REL_TOL = 1e-4

@@ -489,7 +489,7 @@ def test_infeasible_qps_of_the_pushed_configuration_are_infeasible_for_the_oracl
     PrimalInfeasible in the bench's timed region (`all_solved: false` there).  On the SAME exported QPs the oracle's solver gives the same
     status -- they are properties of the pushed workload, not failures of the device solver."""
     from oracle_py import qp_solve
-    from bench import config_d_instance
+    from srbm_loader.workloads import config_d_instance
     cfg = load_config('a1_config_distr_rejection')
     N = cfg['num_nodes']; nx = 12 * (N + 1)
     ids = [150, 441, 3]

@@ -118,7 +118,7 @@ def test_device_pointer_entries_of_the_control_tick_equal_the_host_pointer_entri
             hip.hipFree(self.p)
     B = 32
     cfg, q, v, q_des, v_des, rng = make(B, seed=21)
-    from bench import config_b_instance
+    from srbm_loader.workloads import config_b_instance
     states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
     states, ees = np.array(states), np.array(ees).reshape(B, 12)
     g = host.BatchMPC(cfg, B)
