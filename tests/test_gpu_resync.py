@@ -72,9 +72,13 @@ def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None, step_rule=Tr
     for b in range(B):
         so = oracles[b].stats()['status']
         assert cls(st0[b]) == cls(so) or {cls(st0[b]), cls(so)} <= {'solved', 'maxiter'}, (b, st0[b], so)
-    seen_sizes, seen_td, worst = set(), 0, dict(A=0.0, x=0.0, x_inacc=0.0, z=0.0, z_all=0.0, states=0.0, x_cert_oracle=0.0, x_cert_gpu=0.0, dual_obj=0.0, kkt=0.0)
+    seen_sizes, seen_td, worst = set(), 0, dict(A=0.0, x=0.0, x_inacc=0.0, z=0.0, z_all=0.0, Atz=0.0, states=0.0, x_cert_oracle=0.0, x_cert_gpu=0.0, x_cert_gpu_where_oracle_gave_up=0.0,
+                                               dual_obj=0.0, kkt=0.0)
     n_cert = 0
     n_inacc = 0
+    n_atz = 0
+    n_gave_up = n_gave_up_cert = 0
+    inacc_where = []
     n_unique = 0
     exact_status = 0
     total = 0
@@ -115,8 +119,23 @@ def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None, step_rule=Tr
             if not alive[b]:
                 return dict(exact=0, n=0, ntd=0, dead=1)
             if cls(sos[b]) in ('maxiter', 'other'):
+                # The ORACLE's solver gives up on this QP (its iterate is not a minimiser, the instance leaves the comparison from here on) -- but the
+                # DEVICE's answer to it is still checked: where the device reports Solved, its minimiser is certified independently of both
+                # interior-point codes (tests/qp_polish.py: active-set polish of the device's own point on the device's exported QP + KKT certificate)
                 alive[b] = False
-                return dict(exact=0, n=0, ntd=0, dead=1)
+                gave = dict(exact=0, n=0, ntd=0, dead=1, gave_up=1)
+                if int(st[b]) == 0:
+                    from qp_polish import polish
+                    A, bv, P, q = g.export_qp(b)
+                    n_, m_ = int(sz[b, 0]), int(sz[b, 1])
+                    is_eq = np.ones(m_, bool)
+                    is_eq[nx:nx + int(sz[b, 3])] = False
+                    xc, info = polish(P, q, A, bv, is_eq, xr[b, :n_], z[b, :m_], s[b, :m_])
+                    if xc is not None:
+                        gave['gave_up_cert'] = 1
+                        gave['x_cert_gpu_where_oracle_gave_up'] = relerr(xr[b, :n_], xc)
+                        assert gave['x_cert_gpu_where_oracle_gave_up'] < REL_TOL, (i, b, gave['x_cert_gpu_where_oracle_gave_up'])
+                return gave
             osz = o.sizes()
             n, m = osz['n'], osz['m']
             assert (sz[b, 0], sz[b, 1], sz[b, 2], sz[b, 3], sz[b, 4], sz[b, 5], sz[b, 6]) == \
@@ -151,15 +170,13 @@ def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None, step_rule=Tr
                 return out              # an unconverged QP: the iterate it stopped at is solver-specific
             xo = o.x()
             out['x'] = max(relerr(xr[b, :n], o.qp_x()), relerr(x[b, :n], xo))
-            if fused and int(st[b]) == 1:
-                # (fused protocol only: its first step, node 1 of the cold-start trajectory, is a harder QP than the host-driven protocol's.)  The
-                # DEVICE itself reports SolvedInacc (its iteration stalled above the tolerances and it says so): the point it returns is held to
-                # the REDUCED tolerance; such solves are counted and their number is bounded below.  Every other pair keeps the full bound.
+            if int(st[b]) == 1:
+                # the DEVICE itself reports SolvedInacc where the oracle reports Solved: counted, located, and held to the SAME bound as every other
+                # pair (round 4 allowed 10 x here)
                 out['inacc'] = 1
-                assert out['x'] < 10 * x_tol, (i, b, out['x'], int(st[b]), int(sos[b]))
-                out['x_inacc'] = out.pop('x')
-                return out
-            assert out['x'] < x_tol, (i, b, out['x'])
+                out['x_inacc'] = out['x']
+                out['inacc_where'] = (i, b, int(stats[b, 4]), float(out['x']))
+            assert out['x'] < x_tol, (i, b, out['x'], int(st[b]), int(sos[b]))
             out['states'] = relerr(tr[b], o.states())
             assert out['states'] < x_tol, (i, b)
             # a sample is checked against the CERTIFIED minimiser of the QP (tests/qp_polish.py: active-set polish + KKT
@@ -199,6 +216,11 @@ def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None, step_rule=Tr
                 dscale = abs(bo @ zo) if not step_rule else np.abs(bo * zo).sum()
                 out['dual_obj'] = abs(bo @ zg - bo @ zo) / max(1.0, abs(bo @ zo))
                 assert abs(bo @ zg - bo @ zo) <= 1e-6 * max(1.0, dscale), (i, b, bo @ zg, bo @ zo, dscale)
+                # the IDENTIFIABLE part of the multipliers, for EVERY solve: A'z is determined by stationarity (A'z = -(P x + q)) whatever split of
+                # dependent active rows a solver picked -- the projection of z_gpu - z_oracle onto the row space of the constraint matrix
+                out['Atz'] = np.abs(Ao.T @ (zg - zo)).max() / max(1.0, np.abs(Ao.T @ zo).max())
+                out['atz'] = 1
+                assert out['Atz'] < REL_TOL, (i, b, out['Atz'])
                 active = np.ones(m, bool)
                 active[ineq] = so_[ineq] < 1e-7
                 active &= np.abs(Ao).sum(axis=1) > 0      # rows without coefficients constrain nothing
@@ -220,6 +242,8 @@ def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None, step_rule=Tr
         x_by_step.append((float(xs_.max()), int(xs_.argmax()), int((xs_ > REL_TOL).sum())))
         for r in res:
             if r.get('dead'):
+                n_gave_up += r.get('gave_up', 0); n_gave_up_cert += r.get('gave_up_cert', 0)
+                worst['x_cert_gpu_where_oracle_gave_up'] = max(worst['x_cert_gpu_where_oracle_gave_up'], r.get('x_cert_gpu_where_oracle_gave_up', 0.0))
                 continue
             total += 1
             exact_status += r['exact']
@@ -227,6 +251,9 @@ def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None, step_rule=Tr
             n_unique += r.get('z_unique', 0)
             n_cert += r.get('cert', 0)
             n_inacc += r.get('inacc', 0)
+            n_atz += r.get('atz', 0)
+            if 'inacc_where' in r:
+                inacc_where.append(r['inacc_where'])
             for k in worst:
                 if k in r:
                     worst[k] = max(worst[k], r[k])
@@ -239,8 +266,9 @@ def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None, step_rule=Tr
     assert ctr['solves'] == B * steps
     if fused and g.solver_step_rule()[1] > 0:  # the test cannot silently run without attempts
         assert ctr['low_tried'] >= 0.8 * ctr['solves'], ctr
-    assert n_inacc <= max(2, total // 500), (n_inacc, total)          # (observed: 0-1 of 5 120 solves)
-    return dict(inacc=n_inacc, x_by_step=x_by_step, counters=ctr, alive=int(alive.sum()), sizes=seen_sizes, td_steps=seen_td, worst=worst, exact_status=exact_status, total=total, z_unique=n_unique, certified=n_cert)
+    # (a device SolvedInacc where the oracle says Solved is a CLASSIFICATION difference of two interior-point codes at the fp64 floor -- observed on 13 of
+    #  5 102 host-driven solves, all within 6e-11 of the oracle's minimiser; every such pair is held to the full bound above and listed in the result)
+    return dict(inacc=n_inacc, inacc_where=inacc_where, duals_compared_on_row_space=n_atz, oracle_gave_up=n_gave_up, device_certified_where_oracle_gave_up=n_gave_up_cert, x_by_step=x_by_step, counters=ctr, alive=int(alive.sum()), sizes=seen_sizes, td_steps=seen_td, worst=worst, exact_status=exact_status, total=total, z_unique=n_unique, certified=n_cert)
 
 
 def test_config_b_all_256_instances_entrywise_over_20_steps():
@@ -257,7 +285,8 @@ def test_config_b_all_256_instances_entrywise_over_20_steps():
     assert r['td_steps'] > 0                                      # ... and steps with touch-down position rows
     assert r['worst']['A'] <= 1e-12 and r['worst']['x'] < REL_TOL and r['worst']['z'] < REL_TOL and r['worst']['dual_obj'] <= 1e-6
     print('resync parity at the reference criterion, 256 x 20: alive', r['alive'], 'worst', r['worst'], 'exact status matches %d / %d' % (r['exact_status'], r['total']),
-          'duals compared entry-wise (unique multipliers) in %d solves' % r['z_unique'], 'certified minimisers: %d' % r['certified'])
+          'duals compared entry-wise (unique multipliers) in %d solves, on the row space (A\'z) in %d' % (r['z_unique'], r['duals_compared_on_row_space']), 'certified minimisers: %d' % r['certified'],
+          'oracle gave up on %d solves, device certified there: %d' % (r['oracle_gave_up'], r['device_certified_where_oracle_gave_up']), 'device SolvedInacc at', r['inacc_where'])
     assert r['certified'] >= 40
 
 
@@ -277,7 +306,8 @@ def test_config_b_all_256_through_the_fused_launch_with_lower_start_attempts():
     c = r['counters']
     print('resync parity THROUGH THE FUSED LAUNCH, 256 x 20, tol_step 1e-5 / start_mu 0.1: alive', r['alive'], 'worst', r['worst'],
           'solves %d, ended by the step rule %d, began with an attempt %d, attempts repeated %d' % (c['solves'], c['step_rule'], c['low_tried'], c['low_failed']),
-          'certified minimisers: %d' % r['certified'])
+          'certified minimisers: %d' % r['certified'], 'duals on the row space in %d solves' % r['duals_compared_on_row_space'],
+          'oracle gave up on %d solves, device certified there: %d' % (r['oracle_gave_up'], r['device_certified_where_oracle_gave_up']), 'device SolvedInacc at', r['inacc_where'])
     assert c['low_tried'] == c['solves'] and c['step_rule'] >= 0.9 * c['solves']
     assert r['certified'] >= 40
 
@@ -315,9 +345,27 @@ def test_config_b_reference_criterion_with_lower_start_through_the_fused_launch(
     states, ees = np.array(states), np.array(ees)
     r = resync_protocol(cfg, states, ees, steps=12, step_rule=False, fused=True, start_mu=host.FAST_START_MU, min_alive=B - 3)
     c = r['counters']
-    print('resync parity, reference criterion + lower start through the fused launch, 128 x 12: worst', r['worst'], c)
+    print('resync parity, reference criterion + lower start through the fused launch, 128 x 12: worst', r['worst'], c, 'device SolvedInacc at', r['inacc_where'],
+          'duals on the row space in %d solves' % r['duals_compared_on_row_space'])
     assert r['worst']['A'] <= 1e-12 and r['worst']['x'] < REL_TOL and r['worst']['z'] < REL_TOL and r['worst']['dual_obj'] <= 1e-6
     assert c['step_rule'] == 0 and c['low_tried'] == c['solves'] and c["low_failed"] <= 0.4 * c["solves"], c
+
+
+def test_config_b_reference_criterion_through_the_fused_launch():
+    """srbm_set_solver_step_rule(0, 0) THROUGH THE FUSED LAUNCH: the library default -- Clarabel's starting point, Clarabel's
+    criterion, no attempt -- on the protocol the fused launch runs (its first step starts from node 1 of the cold-start trajectory), 64 instances x
+    12 steps with the strict dual bounds.  Separates the fused protocol's QPs from the lower-start attempt: a solve the device cannot finish HERE is
+    the protocol's, not the attempt's."""
+    cfg = load_config()
+    B = 64
+    states, ees = zip(*[config_b_instance(cfg, b) for b in range(B)])
+    states, ees = np.array(states), np.array(ees)
+    r = resync_protocol(cfg, states, ees, steps=12, step_rule=False, fused=True, min_alive=B - 2)
+    c = r['counters']
+    print('resync parity, reference criterion (0, 0) through the fused launch, 64 x 12: worst', r['worst'], c, 'device SolvedInacc at', r['inacc_where'],
+          'duals on the row space in %d solves' % r['duals_compared_on_row_space'])
+    assert r['worst']['A'] <= 1e-12 and r['worst']['x'] < REL_TOL and r['worst']['z'] < REL_TOL and r['worst']['dual_obj'] <= 1e-6
+    assert c['step_rule'] == 0 and c['low_tried'] == 0, c
 
 
 def test_config_c_values_at_n20_entrywise():
