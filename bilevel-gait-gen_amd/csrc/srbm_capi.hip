@@ -495,6 +495,23 @@ int srbm_debug_get_trace(srbm_batch* h, int inst, double* out256) {
     return 0;
 }
 
+// diagnostic: the spline variables of the linearisation point and of the QP minimiser of instance `inst`, with the column descriptors
+// (foot, type 0 force / 1 position, coordinate, local index) and the pin / substitution mask -- scripts/dev_attempts.py
+int srbm_debug_get_spline_step(srbm_batch* h, int inst, double* u_prev, double* u, int* cols4, int* fix) {
+    if (!h || inst < 0 || inst >= h->batch || !u_prev || !u || !cols4 || !fix) return fail("bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const char* W = reinterpret_cast<const char*>(h->works + inst);
+    HIPCHK(hipMemcpy(u_prev, W + offsetof(SrbmWork, u_prev), sizeof(double) * SRBM_NUMAX, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(u, W + offsetof(SrbmWork, u), sizeof(double) * SRBM_NUMAX, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cols4, W + offsetof(SrbmWork, col_ee), sizeof(int) * SRBM_NUMAX, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cols4 + SRBM_NUMAX, W + offsetof(SrbmWork, col_type), sizeof(int) * SRBM_NUMAX, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cols4 + 2 * SRBM_NUMAX, W + offsetof(SrbmWork, col_coord), sizeof(int) * SRBM_NUMAX, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cols4 + 3 * SRBM_NUMAX, W + offsetof(SrbmWork, col_local), sizeof(int) * SRBM_NUMAX, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(fix, W + offsetof(SrbmWork, fix_mask), sizeof(int) * SRBM_NUMAX, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // device buffers + kernel attributes of a batch whose host parameters (h->hp, batch, device) are set; on failure everything
 // allocated so far is released by the caller through free_batch()
 static void free_batch(srbm_batch* h) {

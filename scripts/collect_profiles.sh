@@ -27,7 +27,7 @@ pass pmc_sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE
 # the control-tick kernels of row f3 (targets from the trajectory, whole-body QP): kernel trace of the bench WITH its fourth segment
 rocprofv3 --kernel-trace --stats -d $OUT/trace_f3 -o trace --output-format csv -- python3 bench.py --no-cpu-baseline --no-reference-criterion --extra-workloads 0 --gait-steps 0 --closed-loop-steps 0 > $OUT/bench_f3_under_rocprof.json 2> $OUT/trace_f3.err
 echo "trace_f3 rc=$?" >> $OUT/passes.log
-# round 3: kernel stats of the other workloads and segments, occupancy of the co-resident kernel set, PMC of the control-tick kernels
+# kernel stats of the other workloads and segments, occupancy / wait split of Config D, PMC of the control-tick kernels
 rocprofv3 --kernel-trace --stats -d $OUT/trace_D -o trace --output-format csv -- python3 bench.py --workload D --no-cpu-baseline --closed-loop-steps 0 > $OUT/bench_D_under_rocprof.json 2> $OUT/trace_D.err
 echo "trace_D rc=$?" >> $OUT/passes.log
 rocprofv3 --kernel-trace --stats -d $OUT/trace_E -o trace --output-format csv -- python3 bench.py --workload E --no-cpu-baseline --closed-loop-steps 0 > $OUT/bench_E_under_rocprof.json 2> $OUT/trace_E.err
@@ -43,6 +43,7 @@ echo "pmc_f3_sq1 rc=$?" >> $OUT/passes.log
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/pmc_f3_sq2 -o pmc --output-format csv -- python3 $CMD_F3 > $OUT/bench_pmc_f3_sq2.json 2> $OUT/pmc_f3_sq2.err
 echo "pmc_f3_sq2 rc=$?" >> $OUT/passes.log
 python3 scripts/dev_prof.py > $OUT/phase_shares.txt 2> $OUT/phase_shares.err
+PROF_MODE=ref python3 scripts/dev_prof.py > $OUT/phase_shares_reference_criterion.txt 2>> $OUT/phase_shares.err
 echo "dev_prof rc=$?" >> $OUT/passes.log
 cat $OUT/passes.log
 find $OUT -name "*.csv" | sort

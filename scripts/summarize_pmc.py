@@ -60,7 +60,7 @@ with open(os.path.join(dst, 'timed_region.txt'), 'w') as f:
     f.write('%s: %d launches in the trace (1 warm-up launch of %d steps + %d timed regions of %d steps)\n' % (KERNEL, len(rows), pb['warmup'], repeats, steps))
     med = sorted(ms)[len(ms) // 2]
     f.write('timed-region launches, kernel trace:  %s ms   median %.3f ms = %.4f ms per RTI step (mean %.3f; the first region follows the cold start)\n' % (' '.join('%.3f' % v for v in ms), med, med / steps, sum(ms) / len(ms)))
-    f.write('live HIP-event figures of the same run (bench.py roofline.launch_ms_all): %s ms; the MEDIAN region is what `value` and `roofline` describe: %.3f ms\n' % (' '.join('%.3f' % v for v in pb['roofline'].get('launch_ms_all', [])), pb['roofline']['avg_launch_ms']))
+    f.write('live HIP-event figures of the same run (bench.py roofline.launch_ms_all): %s ms; their MEAN is what `roofline` describes (value = sum of the regions): %.3f ms\n' % (' '.join('%.3f' % v for v in pb['roofline'].get('launch_ms_all', [])), pb['roofline']['avg_launch_ms']))
     f.write('unprofiled run: avg_launch_ms %.3f, ms_per_step %.4f, value %.0f it/s\n' % (ub['roofline']['avg_launch_ms'], ub['ms_per_step'], ub['value']))
 
 
@@ -77,19 +77,19 @@ def counters(sub):
         if KERNEL in r['Kernel_Name']:
             d = per.setdefault(r['Counter_Name'], {})
             d[int(r['Dispatch_Id'])] = d.get(int(r['Dispatch_Id']), 0.0) + float(r['Counter_Value'])
-    # the launch `value` and `roofline` describe: the MEDIAN region of the timed five (same deterministic workload in every pass, so the same launch)
+    # what `value` and `roofline` describe since round 5: ALL timed launches (mean per launch; same deterministic workload in every pass)
     out = {}
     for c, d in per.items():
         ids = sorted(d)[-repeats:]
-        out[c] = d[ids[MED_IDX]] if MED_IDX < len(ids) else sum(d[i] for i in ids) / len(ids)
+        out[c] = sum(d[i] for i in ids) / len(ids)
     return out
 
 
 F, W, S1, S2 = counters('pmc_fetch'), counters('pmc_write'), counters('pmc_sq1'), counters('pmc_sq2')
 summ = {'kernel': KERNEL, 'round': rnd, 'kernel_source_sha': bench.kernel_source_sha(), 'steps_per_launch': steps, 'timed_launches': repeats,
         'command': 'rocprofv3 --pmc <one pass per counter group, no other tracing> -- python3 bench.py --no-cpu-baseline --no-reference-criterion --extra-workloads 0 --gait-steps 0 --closed-loop-steps 0 --wbc-ticks 0',
-        'launch_described': 'the median region of the timed five (index %d): counters, duration and the bench line all refer to it' % MED_IDX,
-        'kernel_trace_ms_per_launch': ms[MED_IDX], 'hip_event_ms_per_launch_same_run': pb['roofline']['avg_launch_ms'],
+        'launch_described': 'mean over the %d timed launches (one per region): counters, duration and the roofline object of the bench line all refer to it' % len(ms),
+        'kernel_trace_ms_per_launch': sum(ms) / len(ms), 'kernel_trace_ms_each': ms, 'hip_event_ms_per_launch_same_run': pb['roofline']['avg_launch_ms'],
         'raw_counters_per_launch': {**F, **W, **S1, **S2}}
 if 'FETCH_SIZE' in F and 'WRITE_SIZE' in W:
     hbm = (2.0 * F['FETCH_SIZE'] + W['WRITE_SIZE']) * 1024.0
@@ -104,7 +104,7 @@ if 'SQ_WAVE_CYCLES' in S1:
     # cycles (guide, 's_memtime tick vs SQ PMC units'); GRBM_GUI_ACTIVE is summed over the 8 XCDs
     gui = S1.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
     summ.update({'gpu_cycles_per_launch': gui,
-                 'effective_clock_GHz': gui / (ms[MED_IDX] * 1e6) if gui else None,
+                 'effective_clock_GHz': gui / (sum(ms) / len(ms) * 1e6) if gui else None,
                  'mfma_busy_cycles_per_launch': S1.get('SQ_VALU_MFMA_BUSY_CYCLES'),
                  # 256 CUs x 4 SIMDs each could be busy for every GPU cycle of the launch
                  'mfma_busy_frac': S1.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui * 256 * 4) if gui else None,
@@ -169,8 +169,23 @@ for kn in ('srbm_k_targets_from_traj', 'srbm_k_qp_control'):
                      'wave_cycles_split': {k: a[k] / a['SQ_WAVE_CYCLES'] for k in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY') if k in a and a.get('SQ_WAVE_CYCLES')},
                      'valu_instructions_per_wave': b_.get('SQ_INSTS_VALU', 0.0) / a['SQ_WAVES'] if a.get('SQ_WAVES') else None,
                      'lds_bank_conflict_frac': b_['SQ_LDS_BANK_CONFLICT'] / b_['SQ_LDS_IDX_ACTIVE'] if b_.get('SQ_LDS_IDX_ACTIVE') else None}
+if os.path.exists(os.path.join(src, 'phase_shares_reference_criterion.txt')):
+    shutil.copy(os.path.join(src, 'phase_shares_reference_criterion.txt'), os.path.join(dst, 'ipm_phase_shares_reference_criterion.txt'))
 if os.path.exists(os.path.join(src, 'phase_shares.txt')):
     shutil.copy(os.path.join(src, 'phase_shares.txt'), os.path.join(dst, 'ipm_phase_shares.txt'))
+    # the two numbers rounds are compared by: cycles of one IPM iteration and the share of the dense phase, from the coarse stamps
+    # of the diagnostic build (scripts/dev_prof.py: last solve of instance 0 after 4 RTI steps)
+    try:
+        txt = open(os.path.join(src, 'phase_shares.txt')).read().splitlines()
+        it_line = [l for l in txt if l.startswith('iters ')][0].split()
+        iters, ticks = float(it_line[1]), float(it_line[-1])
+        coarse = txt[:next((i for i, l in enumerate(txt) if l.startswith('fine stamps')), len(txt))]
+        share = {l[:18].strip(): float(l.split()[-1].rstrip('%')) for l in coarse if l.rstrip().endswith('%') and len(l.split()) >= 3}
+        summ['ipm_iteration'] = {'source': 'profiles/%s/ipm_phase_shares.txt (diagnostic build with stamps: shares, not times)' % rnd, 'solver_settings': txt[0],
+                                 'iterations_of_the_solve': iters, 'stamp_ticks_per_iteration': ticks / max(iters, 1.0),
+                                 'cholesky_incl_rank2_and_inverse_share_pct': share.get('Cholesky'), 'coarse_shares_pct': share}
+    except Exception as e:
+        summ['ipm_iteration'] = {'error': str(e)}
 if extra:
     summ['other_kernels'] = extra
 json.dump(summ, open(os.path.join(dst, 'pmc_summary.json'), 'w'), indent=1)
