@@ -18,7 +18,9 @@ g.create_initial_run(st, ee)
 prev_it = g.work_counters()[0]
 tot = np.zeros(B)
 print('mode', g.solver_step_rule())
+even_mu = float(os.environ.get('EVEN_MU', mu))
 for i in range(steps):
+    g.set_solver_step_rule(ts, even_mu if i % 2 == 0 else mu)
     g.rti_advance(i, 1); g.synchronize()
     fl = g.solve_flags()
     it = g.stats()[:, 4]
