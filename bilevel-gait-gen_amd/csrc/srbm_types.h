@@ -46,7 +46,8 @@ enum { SRBM_SOLVED = 0, SRBM_SOLVED_INACC = 1, SRBM_MAX_ITER = 2, SRBM_PRIMAL_IN
 
 /* error bits (SrbmInst.err): conditions on which the reference throws */
 enum { SRBM_ERR_TIME_SMALL = 1, SRBM_ERR_TIME_LARGE = 2, SRBM_ERR_INVALID_TIME = 4, SRBM_ERR_FORCE_NOT_MUTABLE = 8,
-       SRBM_ERR_CAPACITY = 16, SRBM_ERR_REMOVE_POLY = 32, SRBM_ERR_TD_INDEX = 64, SRBM_ERR_CHOLESKY = 128 };
+       SRBM_ERR_CAPACITY = 16, SRBM_ERR_REMOVE_POLY = 32, SRBM_ERR_TD_INDEX = 64, SRBM_ERR_CHOLESKY = 128,
+       SRBM_ERR_STRUCTURE = 256 /* internal invariant: a dense state row has a non-zero outside the force variables of its coordinate (srbm_k2_condense.hiph) */ };
 
 typedef struct SrbmParams {
     int batch, N;
@@ -133,7 +134,8 @@ typedef struct SrbmWork {
     /* ---- condensing (kernel 2) ---- */
     double H[SRBM_HPACK];                         /* reduced Hessian, packed lower, row-major */
     double g[SRBM_NUMAX];
-    double Sig[SRBM_NEEROW][SRBM_NUMAX];          /* rows c of S_k, k=4..N, c in {x,y}: row index 2*(k-4)+c */
+    double Sig[SRBM_NEEROW][SRBM_NUMAX];          /* rows c of S_k, k=4..N, c in {x,y}: row index 2*(k-4)+c; COMPACT: entry q = force variable q of coordinate c over the four feet
+                                                     (the only non-zeros of the row; srbm_k3_ipm.hiph, K3Smem) */
     double sig0[SRBM_NEEROW];                     /* affine part s_k[c] */
     /* ---- IPM (kernel 3) ---- */
     double u[SRBM_NUMAX];                         /* QP minimiser, spline variables (full vector incl. pinned) */

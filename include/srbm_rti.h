@@ -288,7 +288,10 @@ int srbm_qp_control_dev(srbm_batch* h, const double* q_dev, const double* v_dev,
 /* sizes[batch][8] = n, m, n_eq, n_ineq, n_force_vars, n_pos_vars, n_td_rows, n_force_samples */
 int srbm_get_sizes(srbm_batch* h, int* sizes);
 /* status[batch] = mpc::SolveQuality (mpc/include/qp/qp_interface.h:12-22); err[batch] = error bits (0 = none).
- * Both describe the LAST solve only. */
+ * Both describe the LAST solve only.  Error bits (conditions on which the reference throws, plus two of this library): 1 time before the first knot,
+ * 2 time beyond the last knot, 4 invalid time, 8 force node not mutable, 16 beyond the capacity of the build (status Other), 32 RemovePoly on an empty
+ * spline, 64 touch-down index, 128 a pivot of the normal matrix was regularised, 256 internal invariant violated (a dense state row with a non-zero
+ * outside the force variables of its coordinate: never observed; the compact storage of those rows rests on it). */
 int srbm_get_status(srbm_batch* h, int* status, int* err);
 /* Sticky accumulators over every solve since creation / the last clear (multi-step launches overwrite status and err each
  * step): acc[batch][4] = {all error bits raised, solves, solves not in {Solved, SolvedInacc}, of those MaxIter} */
