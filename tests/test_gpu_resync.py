@@ -202,9 +202,10 @@ def resync_protocol(cfg, states, ees, steps, qp_every=1, pool=None, step_rule=Tr
                 zs = max(1.0, np.abs(zo).max())
                 # stationarity of the device's (x, z) on the oracle's QP.  At the gap criterion 1e-7 of |q|; a solve that ends through the step rule
                 # takes its last (affine) step without a corrector, which leaves the multipliers accurate to the order of the primal bound
-                # (DESIGN.md section 3): 1e-5 there (observed worst 1.2e-6, on a solve that began with a lower-start attempt; without attempts 1e-7 holds)
+                # (DESIGN.md section 3), i.e. to the north-star tolerance: 1e-4 there (observed worst 1.2e-6 at N = 20; at N = 40 on the LARGE build one solve sits
+                # at 1e-5 ... 2.4e-5 and moves inside that band with rounding-level changes of the assembly -- round 4 asserted 1e-5 on an observed 9.8e-6)
                 out['kkt'] = np.abs(Po @ xg + qo + Ao.T @ zg).max() / max(1.0, np.abs(qo).max())
-                assert out['kkt'] < (1e-5 if step_rule else 1e-7), (i, b, out['kkt'])
+                assert out['kkt'] < (REL_TOL if step_rule else 1e-7), (i, b, out['kkt'])
                 n_eq0 = nx                               # dynamics rows first, then the inequality blocks, then TD / start rows
                 ineq = slice(nx, nx + osz['n_ineq'])
                 assert zg[ineq].min() > -1e-7 * zs and sg[ineq].min() > -1e-9, (i, b)
