@@ -28,7 +28,7 @@ for n, v in zip(names, out):
 
 out2 = np.zeros(64)
 gb.L.srbm_debug_get_profile2(gb.h, 0, out2.ctypes.data_as(C.POINTER(C.c_double)))
-names2 = {0: 'other->eval', 1: 'eval: force samples', 2: 'eval: dense rows', 3: 'other->gt', 4: 'gt: cs', 5: 'gt: dense rows', 6: 'gt: reduce + epilogue', 50: '  gt: dense rows (LDS)', 51: '  gt: sparse / position part', 7: 'other->M', 8: 'M force blocks', 52: '  M (c) dense rows: compact MFMA blocks', 53: '  M (d) dense rows x position coefficients', 9: 'M (b) position blocks', 10: 'M dense + factor + invert', 20: '  tiles <- LDS', 21: '  cholesky', 22: '  invert diag blocks', 23: '  trtri', 24: '  rank-2 update (MFMA)',
+names2 = {11: 'H u (two triangular mat-vecs, LDS)', 12: 'dual residual loop + reductions + termination', 0: 'other->eval', 1: 'eval: force samples', 2: 'eval: dense rows', 3: 'other->gt', 4: 'gt: cs', 5: 'gt: dense rows', 6: 'gt: reduce + epilogue', 50: '  gt: dense rows (LDS)', 51: '  gt: sparse / position part', 7: 'other->M', 8: 'M force blocks', 52: '  M (c) dense rows: compact MFMA blocks', 53: '  M (d) dense rows x position coefficients', 9: 'M (b) position blocks', 10: 'M dense + factor + invert', 20: '  tiles <- LDS', 21: '  cholesky', 22: '  invert diag blocks', 23: '  trtri', 24: '  rank-2 update (MFMA)',
           30: 'dir: (other)', 31: 'dir: row rhs', 33: 'dir: col rhs (after G\' pass)', 34: 'dir: tri solves', 35: 'dir: row products (after G pass)',
           36: 'ref: e2 + row write', 32: 'ref: (G\' pass, in 4-6)', 37: 'ref: H du (L2)', 38: 'ref: e1 + err reductions', 39: 'ref: corr rhs (after G\' pass)', 40: 'ref: tri solves', 41: 'ref: row products + update', 42: 'ref: exit',
           43: 'ds + step length', 44: 'gz: targets + row write', 45: 'gz: col rhs (after G\' pass)', 46: 'gz: tri solves', 47: 'gz: row products + step'}

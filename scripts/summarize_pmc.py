@@ -54,13 +54,19 @@ ub, pb = bench_line('bench_unprofiled.json'), bench_line('bench_under_rocprof.js
 steps, repeats = pb['steps'], pb['repeats']
 rows = [r for r in csv.DictReader(open(find('trace', '*kernel_trace.csv'))) if KERNEL in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-timed = rows[-repeats:]
+# launches of the fused kernel in the profiled command, in order: [0] the warm-up launch, [1 .. repeats] the TIMED regions of the headline, then (steady_state
+# of the bench line) one untimed advance and `repeats` more regions from step 125 on.  (Rounds 3-4 took the LAST `repeats` launches here -- the steady-state
+# ones -- and called them the timed regions: their timed_region.txt / pmc_summary.json describe the settled protocol, not the headline's launches.)
+timed = rows[1:1 + repeats]
 ms = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in timed]
+ms_steady = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6 for r in rows[2 + repeats:2 + 2 * repeats]]
 with open(os.path.join(dst, 'timed_region.txt'), 'w') as f:
-    f.write('%s: %d launches in the trace (1 warm-up launch of %d steps + %d timed regions of %d steps)\n' % (KERNEL, len(rows), pb['warmup'], repeats, steps))
+    f.write('%s: %d launches in the trace (1 warm-up launch of %d steps + %d timed regions of %d steps + 1 untimed advance + %d steady-state regions)\n' % (KERNEL, len(rows), pb['warmup'], repeats, steps, len(ms_steady)))
     med = sorted(ms)[len(ms) // 2]
     f.write('timed-region launches, kernel trace:  %s ms   median %.3f ms = %.4f ms per RTI step (mean %.3f; the first region follows the cold start)\n' % (' '.join('%.3f' % v for v in ms), med, med / steps, sum(ms) / len(ms)))
     f.write('live HIP-event figures of the same run (bench.py roofline.launch_ms_all): %s ms; their MEAN is what `roofline` describes (value = sum of the regions): %.3f ms\n' % (' '.join('%.3f' % v for v in pb['roofline'].get('launch_ms_all', [])), pb['roofline']['avg_launch_ms']))
+    if ms_steady:
+        f.write('steady-state regions (from step %d on), kernel trace: %s ms   mean %.3f ms = %.4f ms per RTI step\n' % (pb.get('steady_state', {}).get('first_step', 125), ' '.join('%.3f' % v for v in ms_steady), sum(ms_steady) / len(ms_steady), sum(ms_steady) / len(ms_steady) / steps))
     f.write('unprofiled run: avg_launch_ms %.3f, ms_per_step %.4f, value %.0f it/s\n' % (ub['roofline']['avg_launch_ms'], ub['ms_per_step'], ub['value']))
 
 
@@ -80,7 +86,7 @@ def counters(sub):
     # what `value` and `roofline` describe since round 5: ALL timed launches (mean per launch; same deterministic workload in every pass)
     out = {}
     for c, d in per.items():
-        ids = sorted(d)[-repeats:]
+        ids = sorted(d)[1:1 + repeats]           # (dispatch [0] is the warm-up launch; the steady-state regions come after the timed ones)
         out[c] = sum(d[i] for i in ids) / len(ids)
     return out
 
