@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: scripts/kernel_resources.sh bilevel-gait-gen_amd/libsrbm_rti.so  -> per kernel of EVERY gfx950 code object of the library (one per .hip
-# source: srbm_capi.hip, srbm_co.hip): VGPRs, AGPRs, SGPRs, spills, scratch bytes per lane, static LDS
+# source: srbm_capi.hip): VGPRs, AGPRs, SGPRs, spills, scratch bytes per lane, static LDS
 LIB=$1
 T=$(mktemp -d)
 /opt/rocm/lib/llvm/bin/llvm-objcopy -O binary --only-section=.hip_fatbin $LIB $T/fat.bin
