@@ -26,10 +26,11 @@ for i in range(steps):
     it = g.stats()[:, 4]
     alpha = g.stats()[:, 0]
     snorm = g.stats()[:, 3]
+    gapf = g.stats()[:, 7]; byst = gapf > 1e-15
     z_, s_ = g.dual_solution(); sz_ = g.sizes()
     nact = np.mean([(s_[b, 252:252 + sz_[b, 3]] < 1e-7).sum() for b in range(B)])
     tot += it
     tried, failed = int(((fl & 2) != 0).sum()), int(((fl & 4) != 0).sum())
-    print('step %3d  attempts %3d  repeated %3d  iterations/solve mean %.2f max %d   of the repeated: mean %.1f   alpha<1: %d   nu %s  |p| mean %.2f  active rows mean %.1f' % (
-        i, tried, failed, it.mean(), it.max(), it[(fl & 4) != 0].mean() if failed else 0.0, int((alpha < 1).sum()), np.unique(g.sizes()[:, 0]), snorm.mean(), nact))
+    print('step %3d  attempts %3d  repeated %3d  iterations/solve mean %.2f max %d   of the repeated: mean %.1f   alpha<1: %d   nu %s  |p| mean %.2f  active rows mean %.1f  ended above gap 1e-15 (stall exit): %3d, their iterations %.1f vs %.1f' % (
+        i, tried, failed, it.mean(), it.max(), it[(fl & 4) != 0].mean() if failed else 0.0, int((alpha < 1).sum()), np.unique(g.sizes()[:, 0]), snorm.mean(), nact, int(byst.sum()), it[byst].mean() if byst.any() else 0.0, it[~byst].mean() if (~byst).any() else 0.0))
 print('per-instance total iterations over the run: mean %.1f  max %.1f  (the fused launch ends with the max)' % (tot.mean(), tot.max()))
