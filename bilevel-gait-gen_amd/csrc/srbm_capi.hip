@@ -54,6 +54,8 @@ struct srbm_batch {
     bool owns_stream = true;
     size_t k3_lds = 0;
     int n_cu = 0;
+    SrbmQueue* queues = nullptr;     // step queues of multi-step launches of a batch larger than the chip (srbm_fused.hiph), allocated at first use
+    bool queued_ok = true;           // SRBM_NO_STEP_QUEUE=1 in the environment: such launches as one workgroup per instance (A/B, tests)
     bool params_dirty = true;
     // optional HIP-event timing of the dominant kernel (srbm_k3_ipm) on the launch stream
     bool timing = false;
@@ -336,11 +338,11 @@ int srbm_debug_get_profile(srbm_batch* h, int inst, double* out16) {
     HIPCHK(hipMemcpy(out16, reinterpret_cast<const char*>(h->works + inst) + offsetof(SrbmWork, prof), sizeof(double) * 16, hipMemcpyDeviceToHost));
     return 0;
 }
-int srbm_debug_get_profile2(srbm_batch* h, int inst, double* out64) {
+int srbm_debug_get_profile2(srbm_batch* h, int inst, double* out96) {
     if (!h || inst < 0 || inst >= h->batch) return fail("bad arguments");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy(out64, reinterpret_cast<const char*>(h->works + inst) + offsetof(SrbmWork, prof2), sizeof(double) * 64, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out96, reinterpret_cast<const char*>(h->works + inst) + offsetof(SrbmWork, prof2), sizeof(double) * 96, hipMemcpyDeviceToHost));
     return 0;
 }
 // unit-test hook for the dense building blocks: Cholesky of `count` packed lower-triangular n x n matrices, one workgroup each
@@ -518,7 +520,7 @@ static void free_batch(srbm_batch* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    (void)hipFree(h->dp); (void)hipFree(h->insts); (void)hipFree(h->works);
+    (void)hipFree(h->dp); (void)hipFree(h->insts); (void)hipFree(h->works); (void)hipFree(h->queues);
     (void)hipFree(h->d_state); (void)hipFree(h->d_time); (void)hipFree(h->d_ee);
     (void)hipFree(h->d_plant); (void)hipFree(h->d_push_time); (void)hipFree(h->d_push_impulse);
     (void)hipFree(h->d_scratch); (void)hipFree(h->d_wbc); (void)hipHostFree(h->h_stage);
@@ -545,6 +547,8 @@ static int alloc_batch(srbm_batch* h, hipStream_t borrowed_stream) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_ipm_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_rti_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_rti_fused_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_rti_queued), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_rti_queued_long), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k3_normal_matrix), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->k3_lds));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k_gait_sensitivity), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KG_DYN_LDS_BYTES));
 #ifdef SRBM_LARGE
@@ -554,6 +558,7 @@ static int alloc_batch(srbm_batch* h, hipStream_t borrowed_stream) {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(srbm_k4_update), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(K4Shared)));
 #endif
     HIPCHK(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, h->device));
+    { const char* e = std::getenv("SRBM_NO_STEP_QUEUE"); h->queued_ok = !(e && e[0] == '1'); }
     h->params_dirty = true;
     return 0;
 }
@@ -740,7 +745,18 @@ static int launch_fused(srbm_batch* h, int first_index, int steps, SrbmPlantArgs
     // one launch for all steps (double time = i*info.integrator_dt, gait_opt_playground.cpp:84, is formed on the device)
     const bool tm = h->timing && h->ev_used < h->ev_start.size();
     if (tm) HIPCHK(hipEventRecord(h->ev_start[h->ev_used], h->stream));
-    if (h->hp.N <= K3_SHORT_N)
+    // a batch larger than the chip, several steps: a resident grid takes (instance, step) items from the step queues (srbm_fused.hiph)
+    const bool queued = h->queued_ok && h->batch > h->n_cu && steps > 1 && steps < 65536 && h->batch <= SRBM_NQUEUES * (SRBM_QCAP - 1);
+    if (queued) {
+        if (!h->queues) HIPCHK(hipMalloc(&h->queues, sizeof(SrbmQueue) * SRBM_NQUEUES));
+        hipLaunchKernelGGL(srbm_k_queue_init, dim3(SRBM_NQUEUES), dim3(256), 0, h->stream, h->queues, h->batch);
+        if (h->hp.N <= K3_SHORT_N)
+            hipLaunchKernelGGL(srbm_rti_queued, dim3(h->n_cu), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works, first_index, steps,
+                               h->d_state, h->d_time, h->d_ee, pl, h->queues, h->batch);
+        else
+            hipLaunchKernelGGL(srbm_rti_queued_long, dim3(h->n_cu), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works, first_index, steps,
+                               h->d_state, h->d_time, h->d_ee, pl, h->queues, h->batch);
+    } else if (h->hp.N <= K3_SHORT_N)
         hipLaunchKernelGGL(srbm_rti_fused, dim3(h->batch), dim3(K3_THREADS), h->k3_lds, h->stream, h->dp, h->insts, h->works, first_index, steps,
                            h->d_state, h->d_time, h->d_ee, pl);
     else
@@ -1186,6 +1202,14 @@ int srbm_get_kernel_timings(srbm_batch* h, double* ms_each, int max_launches, in
     HIPCHK(hipStreamSynchronize(h->stream));
     *launches = (int)h->ev_used;
     for (size_t i = 0; i < h->ev_used && (int)i < max_launches; i++) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, h->ev_start[i], h->ev_stop[i])); ms_each[i] = ms; }
+    return 0;
+}
+// per instance: the running total of factorisations (diagnostic: scripts/dev_dispatch_order.py)
+int srbm_debug_get_instance_iters(srbm_batch* h, double* iters /* [batch] */) {
+    if (!h || !iters) return fail("bad arguments");
+    std::vector<SrbmInst> v;
+    if (fetch_insts(h, v)) return -1;
+    for (int b = 0; b < h->batch; b++) iters[b] = v[b].acc_iters;
     return 0;
 }
 int srbm_get_work_counters(srbm_batch* h, double* total_ipm_iterations, double* total_algorithmic_flops) {

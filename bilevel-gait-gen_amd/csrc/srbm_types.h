@@ -47,7 +47,8 @@ enum { SRBM_SOLVED = 0, SRBM_SOLVED_INACC = 1, SRBM_MAX_ITER = 2, SRBM_PRIMAL_IN
 /* error bits (SrbmInst.err): conditions on which the reference throws */
 enum { SRBM_ERR_TIME_SMALL = 1, SRBM_ERR_TIME_LARGE = 2, SRBM_ERR_INVALID_TIME = 4, SRBM_ERR_FORCE_NOT_MUTABLE = 8,
        SRBM_ERR_CAPACITY = 16, SRBM_ERR_REMOVE_POLY = 32, SRBM_ERR_TD_INDEX = 64, SRBM_ERR_CHOLESKY = 128,
-       SRBM_ERR_STRUCTURE = 256 /* internal invariant: a dense state row has a non-zero outside the force variables of its coordinate (srbm_k2_condense.hiph) */ };
+       SRBM_ERR_STRUCTURE = 256 /* internal invariant: a dense state row has a non-zero outside the force variables of its coordinate (srbm_k2_condense.hiph) */,
+       SRBM_ERR_QUEUE = 512 /* a bounded wait of the step queue of a batch larger than the chip ran out (srbm_fused.hiph: srbm_rti_queued) */ };
 
 typedef struct SrbmParams {
     int batch, N;
@@ -152,7 +153,7 @@ typedef struct SrbmWork {
     double Ms[SRBM_HPACK];                        /* gait step: H + G' diag(lambda/s) G of the last solution (srbm_k3_normal_matrix) */
     double w0[SRBM_MIMAX];                        /* IPM: unit weight of the row/cost-scaled problem, e_r^2 / c (kernel 3 scratch) */
     double hrow_g[SRBM_MIMAX];                    /* IPM: right-hand sides of the inequality rows (large build: read from here instead of held in registers) */
-    double prof2[64];                             /* diagnostic builds only: fine-grained stamps (K3_FINE) */
+    double prof2[96];                             /* diagnostic builds only: fine-grained stamps (K3_FINE) */
     double prof[16];                              /* diagnostic builds only (-DSRBM_PROFILE): cycles per IPM phase */
     double dbg[4 * 64];
     double dbg2[4 * 32];                          /* diagnostic builds only: worst refinement row (index, s, lambda, e2) */                           /* diagnostic builds only: per-iteration (mu, alpha_aff, alpha, gap_rel) */

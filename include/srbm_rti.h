@@ -98,7 +98,11 @@ int srbm_get_real_time_update(srbm_batch* h, const double* state, const double* 
 int srbm_get_real_time_update_dev(srbm_batch* h, const double* state_dev, const double* init_time_dev, const double* ee_dev);
 /* Device-resident open-loop protocol of test/gait_opt_playground.cpp:113-126: `steps` RTI iterations with
  * state := node 1 of the previous trajectory, foot locations := previous trajectory at t, t_i = (first_index+i)*dt.
- * No host round trip between iterations.  Asynchronous; srbm_synchronize() to wait. */
+ * No host round trip between iterations.  Asynchronous; srbm_synchronize() to wait.
+ * A batch of at most one instance per CU runs as one workgroup per instance for all steps; a LARGER batch with steps > 1 runs on a resident grid
+ * that takes (instance, step) items from per-XCD queues (csrc/srbm_fused.hiph: the launch no longer ends with the instance whose `steps` solves
+ * happen to be the longest) -- bitwise the same results (tests/test_gpu_queue.py); SRBM_NO_STEP_QUEUE=1 in the environment at srbm_create time
+ * selects the first form for every batch.  The same holds for srbm_closed_loop_advance. */
 int srbm_rti_advance(srbm_batch* h, int first_index, int steps);
 /* same protocol with one kernel launch per phase and step (A/B measurements against the fused kernel) */
 int srbm_rti_advance_unfused(srbm_batch* h, int first_index, int steps);
@@ -291,7 +295,8 @@ int srbm_get_sizes(srbm_batch* h, int* sizes);
  * Both describe the LAST solve only.  Error bits (conditions on which the reference throws, plus two of this library): 1 time before the first knot,
  * 2 time beyond the last knot, 4 invalid time, 8 force node not mutable, 16 beyond the capacity of the build (status Other), 32 RemovePoly on an empty
  * spline, 64 touch-down index, 128 a pivot of the normal matrix was regularised, 256 internal invariant violated (a dense state row with a non-zero
- * outside the force variables of its coordinate: never observed; the compact storage of those rows rests on it). */
+ * outside the force variables of its coordinate: never observed; the compact storage of those rows rests on it), 512 a bounded wait of the step
+ * queue ran out (multi-step launches of a batch larger than the chip hand out (instance, step) items to a resident grid; never observed). */
 int srbm_get_status(srbm_batch* h, int* status, int* err);
 /* Sticky accumulators over every solve since creation / the last clear (multi-step launches overwrite status and err each
  * step): acc[batch][4] = {all error bits raised, solves, solves not in {Solved, SolvedInacc}, of those MaxIter} */

@@ -26,13 +26,18 @@ print('iters', gb.stats()[0, 4], 'total stamp ticks %.0f' % tot)
 for n, v in zip(names, out):
     print('%-18s %10.0f  %5.1f%%' % (n, v, 100 * v / tot))
 
-out2 = np.zeros(64)
+out2 = np.zeros(96)
 gb.L.srbm_debug_get_profile2(gb.h, 0, out2.ctypes.data_as(C.POINTER(C.c_double)))
 names2 = {11: 'H u (two triangular mat-vecs, LDS)', 12: 'dual residual loop + reductions + termination', 0: 'other->eval', 1: 'eval: force samples', 2: 'eval: dense rows', 3: 'other->gt', 4: 'gt: cs', 5: 'gt: dense rows', 6: 'gt: reduce + epilogue', 50: '  gt: dense rows (LDS)', 51: '  gt: sparse / position part', 7: 'other->M', 8: 'M force blocks', 52: '  M (c) dense rows: compact MFMA blocks', 53: '  M (d) dense rows x position coefficients', 9: 'M (b) position blocks', 10: 'M dense + factor + invert', 20: '  tiles <- LDS', 21: '  cholesky', 22: '  invert diag blocks', 23: '  trtri', 24: '  rank-2 update (MFMA)',
           30: 'dir: (other)', 31: 'dir: row rhs', 33: 'dir: col rhs (after G\' pass)', 34: 'dir: tri solves', 35: 'dir: row products (after G pass)',
           36: 'ref: e2 + row write', 32: 'ref: (G\' pass, in 4-6)', 37: 'ref: H du (L2)', 38: 'ref: e1 + err reductions', 39: 'ref: corr rhs (after G\' pass)', 40: 'ref: tri solves', 41: 'ref: row products + update', 42: 'ref: exit',
           43: 'ds + step length', 44: 'gz: targets + row write', 45: 'gz: col rhs (after G\' pass)', 46: 'gz: tri solves', 47: 'gz: row products + step'}
+print('phases between two solves in the fused launch, ticks per RTI step (4 steps): update %.0f, next inputs %.0f, assemble %.0f, condense %.0f; IPM solve of the last step %.0f' % (out2[56] / 4, out2[57] / 4, out2[58] / 4, out2[59] / 4, tot))
 print('fine stamps (accumulated over all RTI steps of this process; shares of their sum):')
-out2[7] = 0; tot2 = out2.sum()
+k1n = ['staging of the knot tables', 'horizon shift', 'variable bookkeeping', 'linearisation point + column map', 'node records + force samples', 'equality rows', 'node blocks + affine term']
+k4n = ['staging, F/R values, B u', 'rollout', 'costates', 'assemble + position-row duals', 'candidates', 'spline-variable cost', 'directional derivative + Armijo', 'x update + states', 'spline node values']
+print('kernel-1 phases (ticks, all steps of this process): ' + '; '.join('%s %.0f' % (n, v) for n, v in zip(k1n, out2[64:71])))
+print('kernel-4 phases (ticks, all steps of this process): ' + '; '.join('%s %.0f' % (n, v) for n, v in zip(k4n, out2[72:81])))
+out2[7] = 0; out2[56:] = 0; tot2 = out2.sum()
 for k, n in names2.items():
     print('%-28s %12.0f %5.1f%%' % (n, out2[k], 100 * out2[k] / tot2))
