@@ -440,6 +440,12 @@ def main():
                 rr = run_protocol(cfg, make_instance, B, False, mo, args.warmup, args.steps, args.repeats)
                 other[mo] = summary(rr, args.steps, 'Config B, same protocol: ' + MODE_TEXT[mo])
                 del rr
+        # the same steps of the headline's mode as ONE region (one launch of steps x repeats steps, one all-gather): what the four synchronisation
+        # points between the regions of `value` cost -- at each of them the batch waits for the instance whose 20 solves happened to be the longest
+        if args.repeats > 1:
+            rr = run_protocol(cfg, make_instance, B, False, MODE, args.warmup, args.steps * args.repeats, 1)
+            other['one_region'] = summary(rr, args.steps * args.repeats, 'Config B, the %d steps of `value` as ONE timed region (one launch): ' % (args.steps * args.repeats) + MODE_TEXT[MODE])
+            del rr
     # ---- BASELINE configs 4 and 5 at their per-GPU sizes, the same protocol with the same --steps / --warmup / --repeats, in the headline's mode
     # (Config D also in the step-rule mode: the number rounds 3-4 tracked) ----
     d_stats = e_stats = None
@@ -730,7 +736,7 @@ def main():
                                   'note': 'rank 0, all solves since the accumulators were cleared (timed regions; include/srbm_rti.h srbm_set_solver_step_rule)'}},
             'roofline': roof,
         }
-        for mo, key in (('reference', 'reference_criterion'), ('lower_start', 'reference_criterion_lower_start'), ('step_rule', 'step_rule_mode')):
+        for mo, key in (('reference', 'reference_criterion'), ('lower_start', 'reference_criterion_lower_start'), ('step_rule', 'step_rule_mode'), ('one_region', 'one_region')):
             if mo in other:
                 out[key] = other[mo]
         if d_stats is not None:

@@ -10,11 +10,12 @@ if len(sys.argv) > 1 and sys.argv[1] == '--child':
     from srbm_loader import workloads as bench
     wl = os.environ.get('AB_WORKLOAD', 'B')
     cfg = host.load_config() if wl == 'B' else host.load_config('a1_config_distr_rejection')
-    B = 256 if wl == 'B' else 512
+    B = int(os.environ.get('AB_BATCH', 256 if wl == 'B' else 512))
+    mod = int(os.environ.get('AB_MOD', 1 << 30))          # AB_MOD=32: the batch is copies of the first 32 instances (same slowest instance at every batch size)
     if wl == 'B':
-        states, ees = zip(*[bench.config_b_instance(cfg, b) for b in range(B)])
+        states, ees = zip(*[bench.config_b_instance(cfg, b % mod) for b in range(B)])
     else:
-        states, ees = zip(*[bench.config_d_instance(cfg, b) for b in range(B)])
+        states, ees = zip(*[bench.config_d_instance(cfg, b % mod) for b in range(B)])
     states, ees = np.array(states), np.array(ees).reshape(B, 12)
     g = host.BatchMPC(cfg, B); g.set_state_trajectory_warm_start(states)
     if 'AB_TOL' in os.environ: g.set_solver_tolerances(float(os.environ['AB_TOL']), float(os.environ['AB_TOL']), 1e-10, 200)

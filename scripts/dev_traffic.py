@@ -17,6 +17,7 @@ if len(sys.argv) > 2 and sys.argv[1] == '--summarize':
         print('%s (KB per instance-step, x %.0f correction applied; last %d launches of each kernel, 256 instances)' % (name, mult, STEPS))
         tot = 0
         for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1][-STEPS:])):
+            if not k.startswith('srbm_k') or len(v) < STEPS: continue        # (the per-phase kernels of the timed steps only: the warm-up's fused launch, fills and copies left out)
             s = sum(v[-STEPS:]) * mult / (STEPS * 256); tot += s
             print('  %-40s launches %4d  %10.1f' % (k[:40], len(v), s))
         print('  %-40s %26.1f' % ('sum', tot))

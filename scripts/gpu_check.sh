@@ -11,7 +11,7 @@ python - <<PY
 import json
 d=json.loads([l for l in open('$D/bench.json') if l.startswith('{')][0])
 print('value', d['value'], d['solver_mode'], 'ms/step', d['ms_per_step'], 'regions', d['region_ms'], 'median-based', d['median_region']['value'], 'steady', d.get('steady_state',{}).get('value'))
-for k in ('reference_criterion','step_rule_mode','config_d','config_e'):
+for k in ('reference_criterion','step_rule_mode','one_region','config_d','config_e'):
     if k in d: print(k, d[k]['value'], d[k]['value_from_median_region'], d[k]['ms_per_step'], d[k]['mean_ipm_iterations'], d[k]['all_solved'])
 if 'config_d' in d and 'step_rule_mode' in d['config_d']: print('config_d step rule', d['config_d']['step_rule_mode']['value'], d['config_d']['step_rule_mode']['value_from_median_region'])
 print('gait', d.get('gait',{}).get('ms_per_step'), 'gait step-rule', d.get('gait',{}).get('step_rule_mode',{}).get('ms_per_step'), 'cl', d.get('closed_loop',{}).get('rti_iterations_per_s'), 'wbc', d.get('wbc',{}).get('device_resident',{}).get('ms_per_tick_of_the_batch'))

@@ -156,11 +156,11 @@ def counters_of(sub, kernel_sub):
 
 
 extra = {}
-cd = counters_of('pmc_D_sq1', 'srbm_rti_fused')
+cd = counters_of('pmc_D_sq1', 'srbm_rti_queued')          # (batches larger than the chip run on the step queues since round 5: srbm_fused.hiph)
 if cd:
     c, nd = cd
     gui = c.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
-    extra['config_D'] = {'kernel': 'srbm_rti_fused_long (512 instances on 256 CUs, standard kernel set since round 4: two rounds)', 'dispatches_averaged': nd, 'raw_counters_per_launch': c,
+    extra['config_D'] = {'kernel': 'srbm_rti_queued_long (512 instances: a resident grid of 256 workgroups takes (instance, step) items from the per-XCD queues; the cold starts and the warm-up of the run are not in it)', 'dispatches_averaged': nd, 'raw_counters_per_launch': c,
         'waves_launched_per_launch': c.get('SQ_WAVES'),
         'occupancy_waves_per_cu': 4.0 * c['SQ_WAVE_CYCLES'] / (gui * 256) if gui and 'SQ_WAVE_CYCLES' in c else None,
         'mfma_busy_frac': c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui * 256 * 4) if gui else None,
