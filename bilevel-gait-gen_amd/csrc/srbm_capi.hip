@@ -304,6 +304,11 @@ static void inv3(const double* m, double* r) {
 }
 // one RTI step as four launches.  exact: the solve is taken to the gap criterion whatever the batch's step rule says (the solve whose KKT
 // sensitivity the gait step differentiates)
+// One RTI step on inputs already in h->d_state / d_time / d_ee: four kernels.  exact: to the gap criterion whatever the batch's step rule says (the solve a gait
+// gradient differentiates).
+// (Measured in round 5: the same step as ONE launch of the fused kernel -- no grid-wide wait between the phases, a workgroup through with its line-search
+//  candidate takes the next one -- is SLOWER: gait segment 7.06 -> 7.34 ms per step; the stand-alone IPM kernel is an entry function -- its uniform
+//  loads are scalar, it spills less (scratch 396 B per lane against 988) -- and that outweighs three kernel tails.)
 static int launch_step(srbm_batch* h, bool exact = false) {
     if (upload_params(h)) return -1;
     // (start_mu only in the fused K-step launches: the lower-start attempt trades a shorter mean for a longer tail, and a one-step launch ends with

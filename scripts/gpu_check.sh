@@ -6,6 +6,8 @@ mkdir -p $D
 timeout -k 10 1000 python -m pytest tests -m gpu -q -s > $D/gpu_tests.log 2>&1
 rc=$?
 tail -8 $D/gpu_tests.log
+# a crashed or killed test run (GPU fault, timeout): no further GPU step in this call
+if [ $rc -ge 124 ] || grep -q "Memory access fault" $D/gpu_tests.log; then echo "test run crashed (rc $rc): bench not started"; exit 1; fi
 timeout -k 10 400 python bench.py > $D/bench.json 2> $D/bench.err || { tail -20 $D/bench.err; exit 1; }
 python - <<PY
 import json
