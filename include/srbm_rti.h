@@ -281,7 +281,9 @@ int srbm_set_wbc_model(srbm_batch* h, const srbm_wbc_model* model);
  * force_des[batch][12] = 3 per foot IN CONTACT, stacked in foot order (the reference's force_target_).
  * control[batch][36] = joint position targets (12), joint velocity targets (12), torques (12) -- all zero where the QP failed, as the
  * reference returns; qp_sol[batch][30] = accelerations (18) then contact forces; status[batch] = SolveQuality | iterations << 8.
- * qp_dump (may be NULL): the assembled QP in the reference's layout per instance: A[50][30], lb[50], ub[50], diag P[30], w[30]. */
+ * qp_dump (may be NULL): the assembled QP in the reference's layout per instance: A[50][30], lb[50], ub[50], diag P[30], w[30].
+ * The solver relies on the rows being the controller's (every torque row and every contact-force row two-sided): with a torque bound or max_grf of
+ * exactly zero such a row is an equality, and the instance is reported with status 8 (SRBM_OTHER) and a zero control action. */
 int srbm_qp_control(srbm_batch* h, const double* q, const double* v, const int* contact, const double* q_des, const double* v_des,
                     const double* force_des, double* control, double* qp_sol, int* status, double* qp_dump);
 /* ... on device pointers: control_dev[batch][36], qp_sol_dev[batch][30], status_dev[batch]; one launch, no copy, no synchronisation */

@@ -45,5 +45,7 @@ echo "pmc_f3_sq2 rc=$?" >> $OUT/passes.log
 python3 scripts/dev_prof.py > $OUT/phase_shares.txt 2> $OUT/phase_shares.err
 PROF_MODE=ref python3 scripts/dev_prof.py > $OUT/phase_shares_reference_criterion.txt 2>> $OUT/phase_shares.err
 echo "dev_prof rc=$?" >> $OUT/passes.log
+SRBM_RTI_LIB=bilevel-gait-gen_amd/libsrbm_rti_prof.so python3 scripts/dev_prof_wbc.py > $OUT/wbc_phase_shares.txt 2>> $OUT/phase_shares.err
+echo "dev_prof_wbc rc=$?" >> $OUT/passes.log
 cat $OUT/passes.log
 find $OUT -name "*.csv" | sort

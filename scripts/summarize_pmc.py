@@ -175,6 +175,8 @@ for kn in ('srbm_k_targets_from_traj', 'srbm_k_qp_control'):
                      'wave_cycles_split': {k: a[k] / a['SQ_WAVE_CYCLES'] for k in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY') if k in a and a.get('SQ_WAVE_CYCLES')},
                      'valu_instructions_per_wave': b_.get('SQ_INSTS_VALU', 0.0) / a['SQ_WAVES'] if a.get('SQ_WAVES') else None,
                      'lds_bank_conflict_frac': b_['SQ_LDS_BANK_CONFLICT'] / b_['SQ_LDS_IDX_ACTIVE'] if b_.get('SQ_LDS_IDX_ACTIVE') else None}
+if os.path.exists(os.path.join(src, 'wbc_phase_shares.txt')):
+    shutil.copy(os.path.join(src, 'wbc_phase_shares.txt'), os.path.join(dst, 'wbc_phase_shares.txt'))
 if os.path.exists(os.path.join(src, 'phase_shares_reference_criterion.txt')):
     shutil.copy(os.path.join(src, 'phase_shares_reference_criterion.txt'), os.path.join(dst, 'ipm_phase_shares_reference_criterion.txt'))
 if os.path.exists(os.path.join(src, 'phase_shares.txt')):

@@ -169,3 +169,17 @@ def test_a_clone_carries_the_whole_body_model_and_close_releases_borrowers_first
     assert not g.h and gait.g is None
     c.close()
     assert not c.h
+
+
+def test_a_row_structure_the_assembly_does_not_cover_is_reported():
+    """The iteration's assembly relies on the controller's row order (12 two-sided torque rows, 4 friction rows and one two-sided force row per foot in
+    contact).  A zero torque bound turns a torque row into an equality and breaks that order: the kernel reports it (status 8, zero control action --
+    the path of "Could not solve WBC QP. Returning 0 control action.", qp_control.cpp:88-92) instead of assembling the wrong matrix"""
+    B = 4
+    cfg, q, v, q_des, v_des, rng = make(B, seed=11)
+    cfg = dict(cfg); cfg['torque_bounds'] = list(cfg['torque_bounds']); cfg['torque_bounds'][3] = 0.0
+    contact = np.ones((B, 4), np.int32)
+    fdes = np.tile([0, 0, cfg['mass'] * 9.81 / 4], (B, 4))
+    g = host.BatchMPC(cfg, B)
+    ctl, sol, st, iters = g.qp_control(q, v, contact, q_des, v_des, fdes)
+    assert np.all(st == 8) and np.all(ctl == 0) and np.all(sol == 0)
