@@ -222,9 +222,15 @@ __global__ __launch_bounds__(SRBM_IK_THREADS) void srbm_k_inverse_kinematics(con
     if (lane < 4) iters[b * 4 + lane] = it[lane];
     if (lane == 0) status[b] = failed;
 }
-__global__ __launch_bounds__(SRBM_IK_THREADS) void srbm_k_targets_from_traj(const SrbmParams* __restrict__ Pp, const SrbmInst* __restrict__ insts, const double* __restrict__ time_in,
+// MPCController::GetTargetsFromTraj: two IK solves per instance -- the targets at `time`, then at time + dt from the first solve's joint angles.
+// TWO WAVES per instance.  Inside a solve the feet are strictly one after the other (they share the base pose), and the second solve takes from the first
+// only the joint angles of a leg as the guess of that leg's foot -- final as soon as the first solve has finished THAT foot.  So wave 1 runs the second
+// solve one foot behind wave 0: five foot slots instead of eight, each wave the same chain of operations on the same data as before (bitwise the same
+// results), on its own SIMD of the CU.
+#define SRBM_TT_THREADS (2 * SRBM_IK_THREADS)
+__global__ __launch_bounds__(SRBM_TT_THREADS) void srbm_k_targets_from_traj(const SrbmParams* __restrict__ Pp, const SrbmInst* __restrict__ insts, const double* __restrict__ time_in,
                                          double* __restrict__ q_des, double* __restrict__ v_des, double* __restrict__ force_des, int* __restrict__ status) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.x, lane = threadIdx.x, wv = threadIdx.x / SRBM_IK_THREADS;
     const SrbmParams& P = *Pp;
     const SrbmInst& I = insts[b];
     const int N = P.N;
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(SRBM_IK_THREADS) void srbm_k_targets_from_traj(cons
     const int node = (int)ceil((time - t0) / dt);
     if (node < 0 || node + 1 > N) { if (lane == 0) status[b] = 2; return; }          // GetState(node + 1) beyond the horizon: the reference's vector access throws
     __shared__ double s1[13], s2[13], ee1[12], ee2[12], F[12], q[19], q2[19];
-    __shared__ int it[4], flags[2];
+    __shared__ int flags[2], ik_failed[2];
     auto T = [&](int k) { return t0 + dt * k; };
     const double* S = I.states;
     if (lane < 2) flags[lane] = 0;
@@ -271,12 +277,35 @@ __global__ __launch_bounds__(SRBM_IK_THREADS) void srbm_k_targets_from_traj(cons
     if (node > 0 && time + dt < T(node)) st = 2;                              // "bad interp."
     if (flags[0]) st = 2;
     const SrbmLegs& L = srbm_legs(P);
-    if (ik_inverse_kinematics(L, s1, ee1, q, it) && st == 0) st = 1;
+    {
+        // SingleRigidBodyModel::InverseKinematics (ik_inverse_kinematics, srbm_ik.hiph) of this wave's solve, foot by foot in step with the other wave
+        const double* st13 = wv ? s2 : s1;
+        const double* eed = wv ? ee2 : ee1;
+        double* qo = wv ? q2 : q;
+        const IkR Rdes = ik_quat_to_R(st13 + 6);
+        const Ik3 pdes = {st13[0], st13[1], st13[2]};
+        double p[3] = {st13[0], st13[1], st13[2]}, qt[4] = {st13[6], st13[7], st13[8], st13[9]};
+        int failed = 0;
+        bool any_success = false;
+        #pragma unroll 1
+        for (int slot = 0; slot < SRBM_NEE + 1; slot++) {
+            const int ee = slot - wv;
+            if (ee >= 0 && ee < SRBM_NEE) {
+                const Ik3 edes = {eed[3 * ee], eed[3 * ee + 1], eed[3 * ee + 2]};
+                double ang[3] = {q[7 + 3 * ee], q[8 + 3 * ee], q[9 + 3 * ee]};        // wave 0: the guess handed in; wave 1: wave 0's result of the slot before
+                bool success;
+                ik_solve_foot(&L.origin[ee][0][0], Rdes, pdes, edes, p, qt, ang, &success);
+                qo[7 + 3 * ee] = ang[0]; qo[8 + 3 * ee] = ang[1]; qo[9 + 3 * ee] = ang[2];
+                any_success = any_success || success;
+                if (!any_success) failed = 1;
+            }
+            __syncthreads();
+        }
+        qo[0] = p[0]; qo[1] = p[1]; qo[2] = p[2]; qo[3] = qt[0]; qo[4] = qt[1]; qo[5] = qt[2]; qo[6] = qt[3];
+        if ((lane & (SRBM_IK_THREADS - 1)) == 0) ik_failed[wv] = failed;
+    }
     __syncthreads();
-    if (lane < 19) q2[lane] = q[lane];
-    __syncthreads();
-    if (ik_inverse_kinematics(L, s2, ee2, q2, it) && st == 0) st = 1;
-    __syncthreads();
+    if ((ik_failed[0] || ik_failed[1]) && st == 0) st = 1;
     double* v = v_des + (size_t)b * 18;
     if (lane < 3) v[lane] = s1[3 + lane] / P.mass;
     else if (lane < 6) { const int i = lane - 3; v[lane] = P.Ir_inv[3 * i] * s1[10] + P.Ir_inv[3 * i + 1] * s1[11] + P.Ir_inv[3 * i + 2] * s1[12]; }
@@ -1849,7 +1878,7 @@ int srbm_get_targets_from_traj(srbm_batch* h, const double* time, double* q_des,
     memcpy(hb, time, sizeof(double) * B);
     memcpy(hb + sizeof(double) * B, q_des, sizeof(double) * 19 * B);
     HIPCHK(hipMemcpyAsync(dv, hb, nin, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(srbm_k_targets_from_traj, dim3(h->batch), dim3(SRBM_IK_THREADS), 0, h->stream, h->dp, h->insts, dt_, dq, dvv, df, dst);
+    hipLaunchKernelGGL(srbm_k_targets_from_traj, dim3(h->batch), dim3(SRBM_TT_THREADS), 0, h->stream, h->dp, h->insts, dt_, dq, dvv, df, dst);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(hb + sizeof(double) * B, dq, total - sizeof(double) * B, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -1867,7 +1896,7 @@ int srbm_get_targets_from_traj_dev(srbm_batch* h, const double* time_dev, double
     if (need_legs(h)) return -1;
     HIPCHK(hipSetDevice(h->device));
     if (upload_params(h)) return -1;
-    hipLaunchKernelGGL(srbm_k_targets_from_traj, dim3(h->batch), dim3(SRBM_IK_THREADS), 0, h->stream, h->dp, h->insts, time_dev, q_des_dev, v_des_dev, force_des_dev, status_dev);
+    hipLaunchKernelGGL(srbm_k_targets_from_traj, dim3(h->batch), dim3(SRBM_TT_THREADS), 0, h->stream, h->dp, h->insts, time_dev, q_des_dev, v_des_dev, force_des_dev, status_dev);
     HIPCHK(hipGetLastError());
     return 0;
 }
